@@ -1,0 +1,166 @@
+/*
+ * lenstrace_hip.h -- C ABI of the MI355X-native lens_trace ray-trace backend (liblenstrace-hip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, POD structs, int status codes, no C++
+ * types and no exceptions.  It carries exactly what the reference's renderer plugin does inside
+ * Renderer::render() (all citations relative to the reference tree):
+ *
+ *   reference step                                                         replaced by
+ *   ---------------------------------------------------------------------  -------------------------
+ *   RendererOpenCL::RendererOpenCL(), device/context/queue                  lt_hip_create
+ *     src/opencl/renderer_opencl.cpp:11-24
+ *   ~RendererOpenCL()                          :26-33                       lt_hip_destroy
+ *   compileKernel(path) + programMap lookup    :35-54, :67-70               lt_hip_program_from_path
+ *     (a kernel *source path* selects the program; here its basename
+ *      selects one of the five pre-compiled HIP programs)
+ *   5 x clCreateBuffer + clEnqueueWriteBuffer  :107-120                     lt_hip_set_scene
+ *     (node / ordered-primitive / material / light-container buffers;
+ *      uploaded once and cached instead of on every render() call)
+ *   camera buffer upload + kernel args + NDRange launches + wait +          lt_hip_render
+ *     blocking read-back into pOutputBuffer    :119-149                     (lt_hip_render_device keeps
+ *                                                                            the pixels in HBM)
+ *   examples/accumulator frame loop + accumulator.frag running mean         frame_count / accumulate
+ *     examples/accumulator/src/main.cpp:296-325, shaders/accumulator.frag   fields of lt_hip_render_desc
+ *   printf("Kernel Error: %d") / build log     :3-9, :142-144               lt_hip_last_error
+ *
+ * Launch semantics are the CUDA backend's (src/cuda/renderer_cuda.cpp:74-88): every pixel of the
+ * W x H image is rendered exactly once, whatever W and H are (the OpenCL backend's truncating
+ * work-block maths, renderer_opencl.cpp:90, is a launch-decomposition artefact the reference's own
+ * CustomBlockSize test declares invisible).
+ *
+ * Buffer layouts are the reference's, verbatim:
+ *   nodes     LinearBVHNode[M] 32 B  include/lens_trace/acceleration_structure_explicit.h:20-32
+ *   prims     Primitive[N]     76 B  :34-42 (BVH order)
+ *   materials Material[K]      32 B  include/lens_trace/model.h:26-31
+ *   lights    LightContainer  260 B  acceleration_structure_explicit.h:44-47
+ *   camera    7 x 4 B                src/camera.cpp:14-19 (frameCount uint in the 7th slot)
+ *   output    float[H][W][depth], 3 floats written per pixel at (y*W+x)*depth
+ */
+#ifndef LENSTRACE_HIP_H
+#define LENSTRACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_HIP_ABI_VERSION 1
+
+typedef struct lt_hip_context lt_hip_context;
+
+/* status codes (0 = success) */
+enum {
+  LT_OK = 0,
+  LT_ERR_INVALID_ARGUMENT = 1,
+  LT_ERR_NO_DEVICE = 2,      /* no usable gfx950 device / HIP runtime failure at create */
+  LT_ERR_HIP = 3,            /* a HIP call failed; text in lt_hip_last_error */
+  LT_ERR_NO_SCENE = 4,       /* render before set_scene */
+  LT_ERR_BAD_SCENE = 5,      /* index out of range, BVH deeper than the reference's 64-entry stack, ... */
+  LT_ERR_BUFFER_TOO_SMALL = 6,
+  LT_ERR_UNKNOWN_PROGRAM = 7
+};
+
+/* the five kernel files the reference ships, selected by kernelFilePath in RenderProperties* */
+enum {
+  LT_PROGRAM_BASIC = 0,                  /* resources/kernels/opencl/basic.cl */
+  LT_PROGRAM_BASIC_LIGHTING = 1,         /* resources/kernels/opencl/basic_lighting.cl (25 blended samples) */
+  LT_PROGRAM_ACCUMULATOR = 2,            /* examples/accumulator/resources/kernels/accumulator.cl */
+  LT_PROGRAM_GLOBAL_ILLUMINATION = 3,    /* examples/global_illumination/resources/kernels/global_illumination.cl */
+  LT_PROGRAM_GLOBAL_ILLUMINATION_25 = 4  /* resources/kernels/opencl/global_illumination.cl (25 blended samples) */
+};
+
+/* KernelMode of include/lens_trace/structures.h:20-23.  Pixels do not depend on it, except that the
+ * lighting programs' linearKernel clamps to [0,1] and their tileKernel does not (accumulator.cl:316-318
+ * vs :356-358). */
+enum { LT_KERNEL_MODE_LINEAR = 0, LT_KERNEL_MODE_TILE = 1 };
+
+enum {
+  LT_RENDER_FLAG_STATS = 1u     /* count rays / node visits / triangle tests with device atomics (slower) */
+};
+
+typedef struct lt_hip_render_desc {
+  uint32_t struct_size;         /* sizeof(lt_hip_render_desc), for ABI growth */
+  int32_t program;              /* LT_PROGRAM_* */
+  int32_t kernel_mode;          /* LT_KERNEL_MODE_* */
+  uint32_t width, height, depth;/* imageDimensions[3]; depth >= 3 */
+  uint8_t camera[28];           /* Camera::getCameraBuffer() */
+  /* Progressive rendering (examples/accumulator/src/main.cpp:296-325).  frame_count == 0: one frame with
+   * the camera buffer's own frameCount, plain overwrite -- exactly Renderer::render().  frame_count > 0:
+   * frames with frameCount = frame_first .. frame_first+frame_count-1; with accumulate != 0 they are folded
+   * into the output by accumulator.frag's running mean acc = (c + acc*n)/(n+1), n = accumulate_base,
+   * accumulate_base+1, ... (n == 0 replaces); with accumulate == 0 the last frame wins. */
+  uint32_t frame_first;
+  uint32_t frame_count;
+  uint32_t accumulate;
+  uint32_t accumulate_base;
+  /* Image-tile sharding (one process per GPU).  The image is cut into tile_w x tile_h tiles, row-major,
+   * edge tiles clipped; this call renders tiles tile_first, tile_first+tile_stride, ... and stores tile k of
+   * the call contiguously at float offset k*tile_w*tile_h*depth, row pitch tile_w (pixels of clipped tiles
+   * outside the image are not written).  tile_w == 0 means "whole image as one tile", which makes the
+   * output layout the reference's (y*W+x)*depth. */
+  uint32_t tile_w, tile_h;
+  uint32_t tile_first, tile_stride;
+  int32_t gi_max_depth;         /* 0 = the reference constant 16 (global_illumination.cl:307) */
+  uint32_t flags;               /* LT_RENDER_FLAG_* */
+} lt_hip_render_desc;
+
+typedef struct lt_hip_stats {
+  uint64_t rays;                /* calls of intersect + intersectIgnorePrimitiveIndex (valid with FLAG_STATS) */
+  uint64_t shadow_rays;
+  uint64_t node_visits;         /* intersectBounds calls */
+  uint64_t tri_tests;           /* intersectTriangle calls */
+  uint64_t pixels;              /* pixels rendered by the last call (per frame) */
+  uint32_t frames;              /* frames rendered by the last call */
+  uint32_t kernel_launches;
+  float kernel_ms;              /* HIP-event time over the kernels of the last call, on the call's stream */
+  float total_ms;               /* lt_hip_render only: upload + kernels + read-back wall time */
+} lt_hip_stats;
+
+int lt_hip_abi_version(void);
+
+/* device_index: HIP ordinal (one context per GPU, one process per GPU under torch.distributed). */
+int lt_hip_create(int device_index, lt_hip_context** out_ctx);
+int lt_hip_destroy(lt_hip_context* ctx);
+
+/* Text of the last error on ctx (or of the last failed lt_hip_create when ctx == NULL). Never NULL. */
+const char* lt_hip_last_error(const lt_hip_context* ctx);
+
+/* Maps RenderProperties*::kernelFilePath to LT_PROGRAM_* by basename ("…/accumulator.cl" -> ACCUMULATOR).
+ * "global_illumination" resolves to the 25-sample program when the path contains "resources/kernels/opencl/"
+ * and does not contain "examples/", as in the reference tree. */
+int lt_hip_program_from_path(const char* kernel_file_path, int* out_program);
+
+/* Uploads (host pointers) and validates the four scene buffers; keeps them resident until the next
+ * set_scene / destroy.  Also builds the traversal-side triangle array (48-byte stride: A, B-A, C-A).  */
+int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims,
+                     uint64_t prim_bytes, const void* materials, uint64_t material_bytes, const void* lights,
+                     uint64_t light_bytes);
+
+/* Number of floats the output of `desc` needs (whole image: W*H*depth; tiled: tiles_of_call*tile_w*tile_h*depth). */
+int lt_hip_output_floats(const lt_hip_render_desc* desc, uint64_t* out_floats);
+
+/* Reference semantics: synchronous, fills caller-owned HOST memory (pOutputBuffer). */
+int lt_hip_render(lt_hip_context* ctx, const lt_hip_render_desc* desc, float* out_host, uint64_t out_bytes);
+
+/* Same, but the pixels stay in HBM: out_device is device memory of the context's GPU, the work is enqueued
+ * on hip_stream (a hipStream_t, NULL = default stream) and NOT waited for. */
+int lt_hip_render_device(lt_hip_context* ctx, const lt_hip_render_desc* desc, float* out_device,
+                         uint64_t out_bytes, void* hip_stream);
+
+/* Scatters a gathered stack of per-rank tile buffers (rank r holds tiles r, r+n_ranks, ...) into the
+ * reference's row-major image.  All pointers are device memory; runs on hip_stream. */
+int lt_hip_untile(lt_hip_context* ctx, const float* gathered, uint64_t floats_per_rank, uint32_t n_ranks,
+                  uint32_t width, uint32_t height, uint32_t depth, uint32_t tile_w, uint32_t tile_h,
+                  float* image_out, void* hip_stream);
+
+int lt_hip_synchronize(lt_hip_context* ctx, void* hip_stream);
+
+/* Statistics of the most recent render call on ctx (waits for it to finish). */
+int lt_hip_get_stats(lt_hip_context* ctx, lt_hip_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LENSTRACE_HIP_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of liblenstrace-hip.so (include/lenstrace_hip.h).  There is NO fallback: if the library is
+missing or a call fails, this raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblenstrace-hip.so")
+
+(LT_OK, LT_ERR_INVALID_ARGUMENT, LT_ERR_NO_DEVICE, LT_ERR_HIP, LT_ERR_NO_SCENE, LT_ERR_BAD_SCENE,
+ LT_ERR_BUFFER_TOO_SMALL, LT_ERR_UNKNOWN_PROGRAM) = range(8)
+STATUS_NAMES = ["LT_OK", "LT_ERR_INVALID_ARGUMENT", "LT_ERR_NO_DEVICE", "LT_ERR_HIP", "LT_ERR_NO_SCENE",
+                "LT_ERR_BAD_SCENE", "LT_ERR_BUFFER_TOO_SMALL", "LT_ERR_UNKNOWN_PROGRAM"]
+
+PROGRAM_BASIC, PROGRAM_BASIC_LIGHTING, PROGRAM_ACCUMULATOR, PROGRAM_GLOBAL_ILLUMINATION, PROGRAM_GLOBAL_ILLUMINATION_25 = range(5)
+KERNEL_MODE_LINEAR, KERNEL_MODE_TILE = 0, 1
+RENDER_FLAG_STATS = 1
+
+# every symbol include/lenstrace_hip.h declares
+EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",
+           "lt_hip_set_scene", "lt_hip_output_floats", "lt_hip_render", "lt_hip_render_device", "lt_hip_untile",
+           "lt_hip_synchronize", "lt_hip_get_stats"]
+
+
+class RenderDesc(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("program", ctypes.c_int32), ("kernel_mode", ctypes.c_int32),
+                ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("depth", ctypes.c_uint32),
+                ("camera", ctypes.c_uint8 * 28),
+                ("frame_first", ctypes.c_uint32), ("frame_count", ctypes.c_uint32), ("accumulate", ctypes.c_uint32),
+                ("accumulate_base", ctypes.c_uint32),
+                ("tile_w", ctypes.c_uint32), ("tile_h", ctypes.c_uint32), ("tile_first", ctypes.c_uint32),
+                ("tile_stride", ctypes.c_uint32),
+                ("gi_max_depth", ctypes.c_int32), ("flags", ctypes.c_uint32)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("rays", ctypes.c_uint64), ("shadow_rays", ctypes.c_uint64), ("node_visits", ctypes.c_uint64),
+                ("tri_tests", ctypes.c_uint64), ("pixels", ctypes.c_uint64), ("frames", ctypes.c_uint32),
+                ("kernel_launches", ctypes.c_uint32), ("kernel_ms", ctypes.c_float), ("total_ms", ctypes.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class LensTraceError(RuntimeError):
+    def __init__(self, code, text):
+        self.code = code
+        name = STATUS_NAMES[code] if 0 <= code < len(STATUS_NAMES) else str(code)
+        super().__init__("%s: %s" % (name, text))
+
+
+_lib = None
+
+
+def load():
+    """Loads liblenstrace-hip.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: the HIP extension is not built (run __graft_entry__.build()); "
+                          "there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+    L.lt_hip_abi_version.restype = i32
+    L.lt_hip_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.lt_hip_destroy.argtypes = [vp]
+    L.lt_hip_last_error.argtypes = [vp]
+    L.lt_hip_last_error.restype = ctypes.c_char_p
+    L.lt_hip_program_from_path.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32)]
+    L.lt_hip_set_scene.argtypes = [vp, vp, u64, vp, u64, vp, u64, vp, u64]
+    L.lt_hip_output_floats.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(u64)]
+    L.lt_hip_render.argtypes = [vp, ctypes.POINTER(RenderDesc), vp, u64]
+    L.lt_hip_render_device.argtypes = [vp, ctypes.POINTER(RenderDesc), vp, u64, vp]
+    L.lt_hip_untile.argtypes = [vp, vp, u64, u32, u32, u32, u32, u32, u32, vp, vp]
+    L.lt_hip_synchronize.argtypes = [vp, vp]
+    L.lt_hip_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    for name in EXPORTS:
+        if name not in ("lt_hip_last_error",):
+            getattr(L, name).restype = i32
+    if L.lt_hip_abi_version() != 1:
+        raise ImportError("liblenstrace-hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def program_from_path(path):
+    out = ctypes.c_int(0)
+    rc = load().lt_hip_program_from_path(path.encode(), ctypes.byref(out))
+    if rc:
+        raise LensTraceError(rc, "no built-in program for kernel file %r" % path)
+    return out.value

@@ -1,0 +1,490 @@
+// lt_capi.hip -- liblenstrace-hip.so: the C ABI of include/lenstrace_hip.h over hand-written gfx950 kernels.
+// Host side of what the reference does in RendererOpenCL::render() (src/opencl/renderer_opencl.cpp:56-153).
+#include "lt_device.hpp"
+
+#include "../../include/lenstrace_hip.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace lt;
+
+// ---------------------------------------------------------------------------------- kernels
+// One lane per pixel; a wavefront covers an 8x8 pixel square, a workgroup 16x16.  Workgroup ids are
+// remapped so that the blocks one XCD receives (ids congruent mod 8) cover one contiguous part of the
+// image: each XCD's private L2 then holds the BVH subtrees of its own image region.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
+  const uint32_t q = n / 8u, r = n % 8u, xcd = b % 8u;
+  return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
+}
+
+template <int PROGRAM, bool DEEP, bool STATS>
+__global__ __launch_bounds__(kBlock) void lt_render_kernel(SceneDev sc, FrameParams fp, float* __restrict__ out,
+                                                          unsigned long long* __restrict__ stats) {
+  __shared__ int lds_stack[kLdsStack * kBlock];
+  Stack<DEEP> st;
+  st.lds = lds_stack + threadIdx.x;
+  Counters c{0, 0, 0, 0};
+
+  const uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t k = b / fp.blocksPerTile, sb = b % fp.blocksPerTile;
+  const uint32_t sbx = sb % fp.blocksPerTileX, sby = sb / fp.blocksPerTileX;
+  const uint32_t tile = fp.tileFirst + k * fp.tileStride;
+  const uint32_t tx = tile % fp.tilesX, ty = tile / fp.tilesX;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t lx = sbx * 16u + (wave & 1u) * 8u + (lane & 7u);
+  const uint32_t ly = sby * 16u + (wave >> 1) * 8u + (lane >> 3);
+  const uint32_t x = tx * fp.tileW + lx, y = ty * fp.tileH + ly;
+  const bool valid = k < fp.tilesInCall && lx < fp.tileW && ly < fp.tileH && x < fp.width && y < fp.height;
+  if (valid) {
+    const V3 color = shade_pixel<PROGRAM, DEEP, STATS>(sc, fp, (int)x, (int)y, st, c);
+    float* o = out + (((size_t)k * fp.tileH + ly) * fp.tileW + lx) * fp.depth;
+    if (fp.accumulateN <= 0) {   // overwrite, or first frame of a running mean (`if (frameCount > 0)` guard)
+      o[0] = color.x; o[1] = color.y; o[2] = color.z;
+    } else {                     // accumulator.frag:12-18: (c + acc*n) / (n+1)
+      const float n = (float)fp.accumulateN, n1 = (float)(fp.accumulateN + 1);
+      o[0] = (color.x + (o[0] * n)) / n1;
+      o[1] = (color.y + (o[1] * n)) / n1;
+      o[2] = (color.z + (o[2] * n)) / n1;
+    }
+  }
+  if (STATS) {
+    atomicAdd(&stats[0], (unsigned long long)c.rays);
+    atomicAdd(&stats[1], (unsigned long long)c.shadow);
+    atomicAdd(&stats[2], (unsigned long long)c.nodes);
+    atomicAdd(&stats[3], (unsigned long long)c.tris);
+  }
+}
+
+// Triangle re-tiling at upload: 76-byte Primitive -> 48-byte (A, B-A, C-A, 0 0 0).
+__global__ void lt_retile_kernel(const float* __restrict__ prims, float4* __restrict__ tris, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = prims + 19 * (size_t)i;
+  const float ax = p[0], ay = p[1], az = p[2];
+  tris[3 * (size_t)i + 0] = make_float4(ax, ay, az, p[3] - ax);
+  tris[3 * (size_t)i + 1] = make_float4(p[4] - ay, p[5] - az, p[6] - ax, p[7] - ay);
+  tris[3 * (size_t)i + 2] = make_float4(p[8] - az, 0.0f, 0.0f, 0.0f);
+}
+
+// Gathered per-rank tile stacks -> row-major image (root side of the one gather per frame).
+__global__ void lt_untile_kernel(const float* __restrict__ gathered, uint64_t floatsPerRank, uint32_t nRanks, uint32_t W,
+                                 uint32_t H, uint32_t depth, uint32_t tileW, uint32_t tileH, uint32_t tilesX,
+                                 float* __restrict__ image) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint64_t)W * H) return;
+  const uint32_t x = (uint32_t)(i % W), y = (uint32_t)(i / W);
+  const uint32_t tx = x / tileW, ty = y / tileH, tile = ty * tilesX + tx;
+  const uint32_t rank = tile % nRanks, k = tile / nRanks;
+  const float* src = gathered + (uint64_t)rank * floatsPerRank +
+                     (((uint64_t)k * tileH + (y - ty * tileH)) * tileW + (x - tx * tileW)) * depth;
+  float* dst = image + i * depth;
+  for (uint32_t ch = 0; ch < depth; ch++) dst[ch] = src[ch];
+}
+
+// ---------------------------------------------------------------------------------- context
+struct lt_hip_context {
+  int device = -1;
+  std::string err;
+  hipStream_t stream = nullptr;      // own stream for lt_hip_render
+  void *d_nodes = nullptr, *d_tris = nullptr, *d_prims = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+  uint32_t n_nodes = 0, n_prims = 0, n_mats = 0;
+  int bvh_height = 0;
+  bool has_scene = false;
+  float* d_out = nullptr;            // staging output for lt_hip_render
+  uint64_t d_out_bytes = 0;
+  unsigned long long* d_stats = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool pending = false, pending_stats = false;
+  lt_hip_stats last{};
+};
+
+static thread_local std::string g_create_error;
+
+#define LT_HIP_CHECK(ctx, call)                                                                     \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                               \
+      return LT_ERR_HIP;                                                                            \
+    }                                                                                               \
+  } while (0)
+
+static int fail(lt_hip_context* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg; else g_create_error = msg;
+  return code;
+}
+
+extern "C" int lt_hip_abi_version(void) { return LT_HIP_ABI_VERSION; }
+
+extern "C" const char* lt_hip_last_error(const lt_hip_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int lt_hip_create(int device_index, lt_hip_context** out_ctx) {
+  if (!out_ctx) return fail(nullptr, LT_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(nullptr, LT_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+  if (device_index < 0 || device_index >= n) return fail(nullptr, LT_ERR_INVALID_ARGUMENT, "device_index out of range");
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device_index)) != hipSuccess)
+    return fail(nullptr, LT_ERR_NO_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(nullptr, LT_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
+  lt_hip_context* ctx = new lt_hip_context();
+  ctx->device = device_index;
+  auto bail = [&](const char* what, hipError_t er) {
+    std::string m = std::string(what) + ": " + hipGetErrorString(er);
+    delete ctx;
+    return fail(nullptr, LT_ERR_HIP, m);
+  };
+  if ((e = hipSetDevice(device_index)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipMalloc((void**)&ctx->d_stats, 4 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  *out_ctx = ctx;
+  return LT_OK;
+}
+
+static void free_scene(lt_hip_context* ctx) {
+  for (void** p : {&ctx->d_nodes, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  ctx->has_scene = false;
+}
+
+extern "C" int lt_hip_destroy(lt_hip_context* ctx) {
+  if (!ctx) return LT_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  free_scene(ctx);
+  if (ctx->d_out) (void)hipFree(ctx->d_out);
+  if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return LT_OK;
+}
+
+extern "C" int lt_hip_program_from_path(const char* path, int* out_program) {
+  if (!path || !out_program) return LT_ERR_INVALID_ARGUMENT;
+  std::string p(path);
+  size_t slash = p.find_last_of('/');
+  std::string base = slash == std::string::npos ? p : p.substr(slash + 1);
+  size_t dot = base.find_last_of('.');
+  if (dot != std::string::npos) base = base.substr(0, dot);
+  if (base == "basic") *out_program = LT_PROGRAM_BASIC;
+  else if (base == "basic_lighting") *out_program = LT_PROGRAM_BASIC_LIGHTING;
+  else if (base == "accumulator") *out_program = LT_PROGRAM_ACCUMULATOR;
+  else if (base == "global_illumination25") *out_program = LT_PROGRAM_GLOBAL_ILLUMINATION_25;
+  else if (base == "global_illumination") {
+    const bool shipped25 = p.find("resources/kernels/opencl/") != std::string::npos && p.find("examples/") == std::string::npos;
+    *out_program = shipped25 ? LT_PROGRAM_GLOBAL_ILLUMINATION_25 : LT_PROGRAM_GLOBAL_ILLUMINATION;
+  } else return LT_ERR_UNKNOWN_PROGRAM;
+  return LT_OK;
+}
+
+// Host-side validation: nothing with an out-of-range index or a cycle may reach a kernel.
+// Returns the BVH height (max number of interior ancestors of a node) or -1 with msg set.
+static int validate_scene(const uint8_t* nodes, uint32_t n_nodes, const uint8_t* prims, uint32_t n_prims, uint32_t n_mats,
+                          const uint8_t* lights, std::string& msg) {
+  struct N { float lo[3], hi[3]; int32_t off; uint16_t cnt; uint8_t axis, pad; };
+  static_assert(sizeof(N) == 32, "LinearBVHNode is 32 bytes");
+  const N* nd = reinterpret_cast<const N*>(nodes);
+  for (uint32_t i = 0; i < n_nodes; i++) {
+    if (nd[i].cnt > 0) {
+      if (nd[i].off < 0 || (uint32_t)nd[i].off >= n_prims) { msg = "leaf primitivesOffset out of range"; return -1; }
+    } else {
+      // pre-order layout: left child = i+1, right child = secondChildOffset > i+1; forward-only => no cycles
+      if (i + 1 >= n_nodes || nd[i].off <= (int32_t)i + 1 || (uint32_t)nd[i].off >= n_nodes) { msg = "interior node children out of range"; return -1; }
+      if (nd[i].axis > 2) { msg = "split axis out of range"; return -1; }
+    }
+  }
+  for (uint32_t i = 0; i < n_prims; i++) {
+    int32_t m;
+    memcpy(&m, prims + 76 * (size_t)i + 72, 4);
+    if (m < 0 || (uint32_t)m >= n_mats) { msg = "materialIndex out of range"; return -1; }
+  }
+  uint32_t lc;
+  memcpy(&lc, lights, 4);
+  if (lc > 64) { msg = "more than 64 emissive triangles"; return -1; }
+  for (uint32_t i = 0; i < lc; i++) {
+    uint32_t p;
+    memcpy(&p, lights + 4 + 4 * i, 4);
+    if (p >= n_prims) { msg = "light primitive out of range"; return -1; }
+  }
+  // height by forward propagation (children always have larger indices than their parent)
+  std::vector<int> depth(n_nodes, -1);
+  depth[0] = 0;
+  int height = 0;
+  for (uint32_t i = 0; i < n_nodes; i++) {
+    if (depth[i] < 0) continue;   // unreachable node: harmless
+    if (depth[i] > height) height = depth[i];
+    if (nd[i].cnt == 0) {
+      depth[i + 1] = depth[i] + 1;
+      depth[nd[i].off] = depth[i] + 1;
+    }
+  }
+  return height;
+}
+
+extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims,
+                                uint64_t prim_bytes, const void* materials, uint64_t material_bytes, const void* lights,
+                                uint64_t light_bytes) {
+  if (!ctx) return LT_ERR_INVALID_ARGUMENT;
+  if (!nodes || !prims || !materials || !lights) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "NULL scene buffer");
+  if (node_bytes == 0 || node_bytes % 32 || prim_bytes == 0 || prim_bytes % 76 || material_bytes == 0 || material_bytes % 32 ||
+      light_bytes != 260)
+    return fail(ctx, LT_ERR_BAD_SCENE, "scene buffer sizes are not whole multiples of LinearBVHNode(32) / Primitive(76) / Material(32) / LightContainer(260)");
+  if (node_bytes / 32 > 0x7fffffffull || prim_bytes / 76 > 0x7fffffffull) return fail(ctx, LT_ERR_BAD_SCENE, "scene too large for int32 indices");
+  const uint32_t n_nodes = (uint32_t)(node_bytes / 32), n_prims = (uint32_t)(prim_bytes / 76), n_mats = (uint32_t)(material_bytes / 32);
+  std::string msg;
+  const int height = validate_scene((const uint8_t*)nodes, n_nodes, (const uint8_t*)prims, n_prims, n_mats, (const uint8_t*)lights, msg);
+  if (height < 0) return fail(ctx, LT_ERR_BAD_SCENE, msg);
+  if (height > kMaxStack) return fail(ctx, LT_ERR_BAD_SCENE, "BVH deeper than the reference's 64-entry traversal stack");
+
+  LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  LT_HIP_CHECK(ctx, hipDeviceSynchronize());
+  free_scene(ctx);
+  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_nodes, node_bytes));
+  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_prims, prim_bytes));
+  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_tris, (size_t)n_prims * 48));
+  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_mats, material_bytes));
+  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_lights, light_bytes));
+  LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_nodes, nodes, node_bytes, hipMemcpyHostToDevice));
+  LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_prims, prims, prim_bytes, hipMemcpyHostToDevice));
+  LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_mats, materials, material_bytes, hipMemcpyHostToDevice));
+  LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_lights, lights, light_bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(lt_retile_kernel, dim3((n_prims + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->d_prims,
+                     (float4*)ctx->d_tris, n_prims);
+  LT_HIP_CHECK(ctx, hipGetLastError());
+  LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->n_nodes = n_nodes;
+  ctx->n_prims = n_prims;
+  ctx->n_mats = n_mats;
+  ctx->bvh_height = height;
+  ctx->has_scene = true;
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------------------------- render
+struct TilePlan {
+  uint32_t tileW, tileH, tilesX, tilesY, tileFirst, tileStride, tilesInCall, bptx, bpty;
+  uint64_t floats;
+};
+
+static int plan_tiles(const lt_hip_render_desc* d, TilePlan& p, std::string& msg) {
+  if (!d || d->struct_size != sizeof(lt_hip_render_desc)) { msg = "bad lt_hip_render_desc (struct_size)"; return LT_ERR_INVALID_ARGUMENT; }
+  if (d->width == 0 || d->height == 0 || d->depth < 3) { msg = "image dimensions must be W>0, H>0, depth>=3"; return LT_ERR_INVALID_ARGUMENT; }
+  if ((uint64_t)d->width * d->height > 0x7fffffffull) { msg = "image too large"; return LT_ERR_INVALID_ARGUMENT; }
+  if (d->tile_w == 0) {
+    p.tileW = d->width; p.tileH = d->height; p.tileFirst = 0; p.tileStride = 1;
+  } else {
+    if (d->tile_h == 0 || d->tile_stride == 0) { msg = "tile_h and tile_stride must be > 0 when tile_w > 0"; return LT_ERR_INVALID_ARGUMENT; }
+    p.tileW = d->tile_w; p.tileH = d->tile_h; p.tileFirst = d->tile_first; p.tileStride = d->tile_stride;
+  }
+  p.tilesX = (d->width + p.tileW - 1) / p.tileW;
+  p.tilesY = (d->height + p.tileH - 1) / p.tileH;
+  const uint32_t total = p.tilesX * p.tilesY;
+  p.tilesInCall = p.tileFirst < total ? (total - p.tileFirst + p.tileStride - 1) / p.tileStride : 0;
+  p.bptx = (p.tileW + 15) / 16;
+  p.bpty = (p.tileH + 15) / 16;
+  p.floats = (uint64_t)p.tilesInCall * p.tileW * p.tileH * d->depth;
+  return LT_OK;
+}
+
+extern "C" int lt_hip_output_floats(const lt_hip_render_desc* desc, uint64_t* out_floats) {
+  TilePlan p;
+  std::string msg;
+  if (!out_floats) return LT_ERR_INVALID_ARGUMENT;
+  int rc = plan_tiles(desc, p, msg);
+  if (rc) return rc;
+  *out_floats = p.floats;
+  return LT_OK;
+}
+
+template <int PROGRAM>
+static void launch_program(bool deep, bool stats, dim3 grid, hipStream_t s, const SceneDev& sc, const FrameParams& fp, float* out,
+                           unsigned long long* st) {
+  if (deep) {
+    if (stats) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, true, true>), grid, dim3(kBlock), 0, s, sc, fp, out, st);
+    else hipLaunchKernelGGL((lt_render_kernel<PROGRAM, true, false>), grid, dim3(kBlock), 0, s, sc, fp, out, st);
+  } else {
+    if (stats) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, false, true>), grid, dim3(kBlock), 0, s, sc, fp, out, st);
+    else hipLaunchKernelGGL((lt_render_kernel<PROGRAM, false, false>), grid, dim3(kBlock), 0, s, sc, fp, out, st);
+  }
+}
+
+static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, float* out_device, uint64_t out_bytes, hipStream_t s) {
+  if (!ctx) return LT_ERR_INVALID_ARGUMENT;
+  if (!ctx->has_scene) return fail(ctx, LT_ERR_NO_SCENE, "lt_hip_render before lt_hip_set_scene");
+  TilePlan p;
+  std::string msg;
+  int rc = plan_tiles(d, p, msg);
+  if (rc) return fail(ctx, rc, msg);
+  if (d->program < LT_PROGRAM_BASIC || d->program > LT_PROGRAM_GLOBAL_ILLUMINATION_25) return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "unknown program");
+  if (d->kernel_mode != LT_KERNEL_MODE_LINEAR && d->kernel_mode != LT_KERNEL_MODE_TILE) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "unknown kernel mode");
+  if (!out_device) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "output pointer is NULL");
+  if (out_bytes < p.floats * sizeof(float)) return fail(ctx, LT_ERR_BUFFER_TOO_SMALL, "output buffer smaller than the image/tile stack");
+  if (d->gi_max_depth < 0 || d->gi_max_depth > 64) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "gi_max_depth out of range");
+  LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+
+  float cam[7];
+  uint32_t camFrame;
+  memcpy(cam, d->camera, 28);
+  memcpy(&camFrame, d->camera + 24, 4);
+
+  SceneDev sc;
+  sc.nodes = (const float4*)ctx->d_nodes;
+  sc.tris = (const float4*)ctx->d_tris;
+  sc.prims = (const float*)ctx->d_prims;
+  sc.mats = (const Material*)ctx->d_mats;
+  sc.lights = (const Lights*)ctx->d_lights;
+  sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_mats = ctx->n_mats;
+
+  FrameParams fp{};
+  fp.camx = cam[0]; fp.camy = cam[1]; fp.camz = cam[2];
+  fp.cosYaw = (float)std::cos((double)cam[3]);
+  fp.sinYaw = (float)std::sin((double)cam[3]);
+  fp.width = d->width; fp.height = d->height; fp.depth = d->depth;
+  fp.clampOutput = d->kernel_mode == LT_KERNEL_MODE_LINEAR;
+  fp.giMaxDepth = d->gi_max_depth ? d->gi_max_depth : 16;
+  fp.tileW = p.tileW; fp.tileH = p.tileH; fp.tilesX = p.tilesX; fp.tileFirst = p.tileFirst; fp.tileStride = p.tileStride;
+  fp.tilesInCall = p.tilesInCall;
+  fp.blocksPerTileX = p.bptx; fp.blocksPerTile = p.bptx * p.bpty;
+
+  const bool stats = (d->flags & LT_RENDER_FLAG_STATS) != 0;
+  const bool deep = ctx->bvh_height > kLdsStack;
+  const uint32_t frames = d->frame_count ? d->frame_count : 1;
+  const uint64_t nblocks = (uint64_t)p.tilesInCall * fp.blocksPerTile;
+  if (nblocks > 0x7fffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many workgroups");
+
+  if (stats) LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), s));
+  LT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, s));
+  uint32_t launches = 0;
+  if (nblocks > 0) {
+    for (uint32_t f = 0; f < frames; f++) {
+      fp.frameCount = d->frame_count ? d->frame_first + f : camFrame;
+      fp.accumulateN = (d->frame_count && d->accumulate) ? (int32_t)(d->accumulate_base + f) : -1;
+      const dim3 grid((uint32_t)nblocks);
+      switch (d->program) {
+        case LT_PROGRAM_BASIC: launch_program<kBasic>(deep, stats, grid, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(deep, stats, grid, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(deep, stats, grid, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(deep, stats, grid, s, sc, fp, out_device, ctx->d_stats); break;
+        default: launch_program<kGI25>(deep, stats, grid, s, sc, fp, out_device, ctx->d_stats); break;
+      }
+      LT_HIP_CHECK(ctx, hipGetLastError());
+      launches++;
+    }
+  }
+  LT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, s));
+  ctx->last = lt_hip_stats{};
+  ctx->last.frames = frames;
+  ctx->last.kernel_launches = launches;
+  // pixels actually inside the image for this call's tiles
+  uint64_t px = 0;
+  for (uint32_t k = 0; k < p.tilesInCall; k++) {
+    const uint32_t tile = p.tileFirst + k * p.tileStride, tx = tile % p.tilesX, ty = tile / p.tilesX;
+    const uint32_t w = std::min(p.tileW, d->width - tx * p.tileW), h = std::min(p.tileH, d->height - ty * p.tileH);
+    px += (uint64_t)w * h;
+  }
+  ctx->last.pixels = px;
+  ctx->last_stream = s;
+  ctx->pending = true;
+  ctx->pending_stats = stats;
+  return LT_OK;
+}
+
+static int finish_pending(lt_hip_context* ctx) {
+  if (!ctx->pending) return LT_OK;
+  LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.0f;
+  LT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  ctx->last.kernel_ms = ms;
+  if (ctx->pending_stats) {
+    unsigned long long h[4];
+    LT_HIP_CHECK(ctx, hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    ctx->last.rays = h[0]; ctx->last.shadow_rays = h[1]; ctx->last.node_visits = h[2]; ctx->last.tri_tests = h[3];
+  }
+  ctx->pending = false;
+  return LT_OK;
+}
+
+extern "C" int lt_hip_render_device(lt_hip_context* ctx, const lt_hip_render_desc* desc, float* out_device, uint64_t out_bytes,
+                                    void* hip_stream) {
+  return render_on_stream(ctx, desc, out_device, out_bytes, (hipStream_t)hip_stream);
+}
+
+extern "C" int lt_hip_render(lt_hip_context* ctx, const lt_hip_render_desc* desc, float* out_host, uint64_t out_bytes) {
+  if (!ctx) return LT_ERR_INVALID_ARGUMENT;
+  if (!out_host) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "output pointer is NULL");
+  TilePlan p;
+  std::string msg;
+  int rc = plan_tiles(desc, p, msg);
+  if (rc) return fail(ctx, rc, msg);
+  const uint64_t need = p.floats * sizeof(float);
+  if (out_bytes < need) return fail(ctx, LT_ERR_BUFFER_TOO_SMALL, "outputBufferSize smaller than W*H*depth floats");
+  const auto t0 = std::chrono::steady_clock::now();
+  LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (ctx->d_out_bytes < need) {
+    if (ctx->d_out) LT_HIP_CHECK(ctx, hipFree(ctx->d_out));
+    ctx->d_out = nullptr;
+    ctx->d_out_bytes = 0;
+    LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_out, need ? need : 4));
+    ctx->d_out_bytes = need;
+  }
+  // a running mean continues from the caller's buffer when accumulate_base > 0
+  if (desc->frame_count && desc->accumulate && desc->accumulate_base > 0)
+    LT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_out, out_host, need, hipMemcpyHostToDevice, ctx->stream));
+  else
+    LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_out, 0, need, ctx->stream));
+  rc = render_on_stream(ctx, desc, ctx->d_out, need, ctx->stream);
+  if (rc) return rc;
+  LT_HIP_CHECK(ctx, hipMemcpyAsync(out_host, ctx->d_out, need, hipMemcpyDeviceToHost, ctx->stream));
+  LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  rc = finish_pending(ctx);
+  if (rc) return rc;
+  ctx->last.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return LT_OK;
+}
+
+extern "C" int lt_hip_untile(lt_hip_context* ctx, const float* gathered, uint64_t floats_per_rank, uint32_t n_ranks, uint32_t width,
+                             uint32_t height, uint32_t depth, uint32_t tile_w, uint32_t tile_h, float* image_out, void* hip_stream) {
+  if (!ctx) return LT_ERR_INVALID_ARGUMENT;
+  if (!gathered || !image_out || !n_ranks || !width || !height || depth < 1 || !tile_w || !tile_h)
+    return fail(ctx, LT_ERR_INVALID_ARGUMENT, "lt_hip_untile: bad argument");
+  const uint32_t tilesX = (width + tile_w - 1) / tile_w, tilesY = (height + tile_h - 1) / tile_h;
+  const uint64_t maxTilesPerRank = ((uint64_t)tilesX * tilesY + n_ranks - 1) / n_ranks;
+  if (floats_per_rank < maxTilesPerRank * tile_w * tile_h * depth) return fail(ctx, LT_ERR_BUFFER_TOO_SMALL, "lt_hip_untile: floats_per_rank too small");
+  LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const uint64_t n = (uint64_t)width * height;
+  hipLaunchKernelGGL(lt_untile_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, gathered,
+                     floats_per_rank, n_ranks, width, height, depth, tile_w, tile_h, tilesX, image_out);
+  LT_HIP_CHECK(ctx, hipGetLastError());
+  return LT_OK;
+}
+
+extern "C" int lt_hip_synchronize(lt_hip_context* ctx, void* hip_stream) {
+  if (!ctx) return LT_ERR_INVALID_ARGUMENT;
+  LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  LT_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)hip_stream));
+  return LT_OK;
+}
+
+extern "C" int lt_hip_get_stats(lt_hip_context* ctx, lt_hip_stats* out) {
+  if (!ctx || !out) return LT_ERR_INVALID_ARGUMENT;
+  int rc = finish_pending(ctx);
+  if (rc) return rc;
+  *out = ctx->last;
+  return LT_OK;
+}

@@ -1,0 +1,495 @@
+// lt_device.hpp -- device-side arithmetic of the lens_trace hot path for gfx950 (CDNA4).
+//
+// Every function states the reference lines it computes (paths relative to the reference tree;
+// "acc.cl" = examples/accumulator/resources/kernels/accumulator.cl, "gi.cl" =
+// examples/global_illumination/resources/kernels/global_illumination.cl, "basic.cl" =
+// resources/kernels/opencl/basic.cl).  This translation unit MUST be compiled with
+// -ffp-contract=off: user-level expressions of the reference are evaluated operation by operation,
+// and the OpenCL builtins are spelled with explicit fmaf() exactly as ROCm's OpenCL device library
+// defines them on gfx950 (dot = fma chain, cross = fma(a,b,-(c*d))); see DESIGN.md "Floating-point
+// model".  hipcc's defaults give IEEE f32 divide / sqrt and keep f32 denormals.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace lt {
+
+constexpr int kBlock = 256;        // threads per workgroup (4 wavefronts of 64)
+constexpr int kLdsStack = 32;      // traversal-stack entries per lane held in LDS
+constexpr int kMaxStack = 64;      // the reference's nodesToVisit[64] (acc.cl:137)
+constexpr float kFltMax = 3.402823466e+38f;
+
+enum Program { kBasic = 0, kBasicLighting = 1, kAccumulator = 2, kGI = 3, kGI25 = 4 };
+
+struct V4 { float x, y, z, w; };
+struct V3 { float x, y, z; };
+struct Ray { V4 o, d; };
+struct Hit { int prim; int hitType; float t, u, v; };   // RayPayload, acc.cl:55-61
+
+struct Material { float diffuse[3]; float ior; float dissolve; float emission[3]; };  // model.h:26-31
+struct Lights { uint32_t count; uint32_t primitives[64]; };                          // acc.cl:45-48
+
+// Scene as it sits in HBM.
+//   nodes : the reference's LinearBVHNode array, verbatim, read as two 16-byte halves per node.
+//   tris  : traversal-side triangles re-tiled at upload, 48-byte stride = 3 x float4:
+//           (A.x A.y A.z e1.x) (e1.y e1.z e2.x e2.y) (e2.z 0 0 0), e1 = B-A, e2 = C-A computed
+//           with the same float subtractions intersectTriangle performs per call (acc.cl:77-78).
+//   prims : the reference's 76-byte Primitive array, verbatim (shading reads positions+normals+material).
+struct SceneDev {
+  const float4* nodes;
+  const float4* tris;
+  const float* prims;       // 19 floats per primitive
+  const Material* mats;
+  const Lights* lights;
+  uint32_t n_nodes, n_prims, n_mats;
+};
+
+struct Counters { uint32_t rays, shadow, nodes, tris; };
+
+// ---------------------------------------------------------------- builtins
+__device__ __forceinline__ V4 mk4(float x, float y, float z, float w) { return V4{x, y, z, w}; }
+__device__ __forceinline__ V4 add4(V4 a, V4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ V4 sub4(V4 a, V4 b) { return mk4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ V4 scale4(float s, V4 a) { return mk4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ V4 neg4(V4 a) { return mk4(-a.x, -a.y, -a.z, -a.w); }
+
+__device__ __forceinline__ float dot4(V4 a, V4 b) {
+  return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
+}
+__device__ __forceinline__ float dot2(float ax, float ay, float bx, float by) { return __builtin_fmaf(ay, by, ax * bx); }
+__device__ __forceinline__ V4 cross4(V4 a, V4 b) {
+  return mk4(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+             __builtin_fmaf(a.x, b.y, -(a.y * b.x)), 0.0f);
+}
+// portable stand-ins for the device library's approximate rsqrt / float trig
+__device__ __forceinline__ float rsqrt_portable(float x) { return (float)(1.0 / sqrt((double)x)); }
+__device__ __forceinline__ float cosf_portable(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float sinf_portable(float x) { return (float)sin((double)x); }
+
+__device__ inline V4 normalize4(V4 p) {
+  if (p.x == 0.0f && p.y == 0.0f && p.z == 0.0f && p.w == 0.0f) return p;
+  float l2 = dot4(p, p);
+  if (l2 < 1.17549435e-38f) {
+    p = scale4(0x1p+86f, p);
+    l2 = dot4(p, p);
+  } else if (l2 == __builtin_inff()) {
+    p = scale4(0x1p-66f, p);
+    l2 = dot4(p, p);
+    if (l2 == __builtin_inff()) {
+      p = mk4(__builtin_copysignf(__builtin_isinf(p.x) ? 1.0f : 0.0f, p.x), __builtin_copysignf(__builtin_isinf(p.y) ? 1.0f : 0.0f, p.y),
+              __builtin_copysignf(__builtin_isinf(p.z) ? 1.0f : 0.0f, p.z), __builtin_copysignf(__builtin_isinf(p.w) ? 1.0f : 0.0f, p.w));
+      l2 = dot4(p, p);
+    }
+  }
+  return scale4(rsqrt_portable(l2), p);
+}
+
+__device__ inline float distance4(V4 a, V4 b) {
+  V4 d = sub4(a, b);
+  float l2 = dot4(d, d);
+  if (l2 < 1.17549435e-38f) {
+    d = scale4(0x1p+86f, d);
+    return __builtin_sqrtf(dot4(d, d)) * 0x1p-86f;
+  } else if (l2 == __builtin_inff()) {
+    d = scale4(0x1p-66f, d);
+    return __builtin_sqrtf(dot4(d, d)) * 0x1p+66f;
+  }
+  return __builtin_sqrtf(l2);
+}
+
+__device__ __forceinline__ float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
+
+// acc.cl:63-66: float dot, then double add / fmod / sin / mul, then float fract
+__device__ inline float random_(float uvx, float uvy, float seed) {
+  float d = dot2(uvx, uvy, 12.9898f, 78.233f);
+  double x = (double)d + 1113.1 * (double)seed;
+  float a = (float)(sin(fmod(x, M_PI)) * 43758.5453);
+  return a - __builtin_floorf(a);
+}
+
+// ---------------------------------------------------------------- traversal
+// acc.cl:72-111 on the re-tiled triangle.  PROGRAM picks the epsilon flavour: basic.cl:78 compares in
+// float against 1e-7f, basic_lighting.cl:4 in double against 1e-7, the others in double against 1e-4.
+template <int PROGRAM>
+__device__ __forceinline__ bool intersect_triangle(const float4* __restrict__ tris, int prim, const Ray& ray, Hit& pl) {
+  const float4* t = tris + 3 * (size_t)prim;
+  float4 t0 = t[0], t1 = t[1], t2 = t[2];
+  V4 A = mk4(t0.x, t0.y, t0.z, 1.0f);
+  V4 v0v1 = mk4(t0.w, t1.x, t1.y, 0.0f);
+  V4 v0v2 = mk4(t1.z, t1.w, t2.x, 0.0f);
+  V4 pvec = cross4(ray.d, v0v2);
+  float det = dot4(v0v1, pvec);
+  if (PROGRAM == kBasic) {
+    if (__builtin_fabsf(det) < 0.0000001f) return false;
+  } else if (PROGRAM == kBasicLighting) {
+    if ((double)__builtin_fabsf(det) < 0.0000001) return false;
+  } else {
+    if ((double)__builtin_fabsf(det) < 0.0001) return false;
+  }
+  float invDet = 1.0f / det;
+  V4 tvec = sub4(ray.o, A);
+  float u = dot4(tvec, pvec) * invDet;
+  if (u < 0.0f || u > 1.0f) return false;
+  V4 qvec = cross4(tvec, v0v1);
+  float v = dot4(ray.d, qvec) * invDet;
+  if (v < 0.0f || u + v > 1.0f) return false;
+  float tt = dot4(v0v2, qvec) * invDet;
+  if (tt < pl.t) {   // no t > 0 test in the reference
+    pl.t = tt; pl.u = u; pl.v = v;
+    return true;
+  }
+  return false;
+}
+
+// The per-lane traversal stack: entries [0,kLdsStack) live in LDS (column `lane`, row stride kBlock, so
+// every wave access is one conflict-free row), deeper entries (only for BVHs deeper than kLdsStack, chosen
+// by the host from the scene's measured height) in a per-lane scratch array.
+template <bool DEEP>
+struct Stack {
+  int* lds;            // &lds_stack[threadIdx.x]
+  int deep[DEEP ? (kMaxStack - kLdsStack) : 1];
+  __device__ __forceinline__ void push(int sp, int v) {
+    if (!DEEP || sp < kLdsStack) lds[sp * kBlock] = v; else deep[sp - kLdsStack] = v;
+  }
+  __device__ __forceinline__ int pop(int sp) {
+    if (!DEEP || sp < kLdsStack) return lds[sp * kBlock];
+    return deep[sp - kLdsStack];
+  }
+};
+
+// acc.cl:132-171 (intersect) and :173-217 (intersectIgnorePrimitiveIndex): same node order (near child
+// first by dirIsNeg[axis]), same box test (acc.cl:113-130, no clipping against the closest hit), leaf =
+// primitives[primitivesOffset] only (the reference's leaf loop never adds i; re-testing the same triangle
+// primitiveCount times leaves the payload unchanged after the first test, so it is tested once here).
+template <int PROGRAM, bool DEEP, bool STATS>
+__device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgnore, int ignore, Hit& pl,
+                                Stack<DEEP>& st, Counters& c) {
+  if (STATS) c.rays++;
+  const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;   // (float)(1.0/(double)x) == 1.0f/x
+  const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
+  int sp = 0, cur = 0;
+  for (;;) {
+    const float4* n = sc.nodes + 2 * (size_t)cur;
+    const float4 a = n[0], b = n[1];   // a = min.x min.y min.z max.x ; b = max.y max.z offset count|axis<<16
+    if (STATS) c.nodes++;
+    float tMin = ((nx ? a.w : a.x) - ray.o.x) * ix;
+    float tMax = ((nx ? a.x : a.w) - ray.o.x) * ix;
+    const float tyMin = ((ny ? b.x : a.y) - ray.o.y) * iy;
+    const float tyMax = ((ny ? a.y : b.x) - ray.o.y) * iy;
+    bool hit = !(tMin > tyMax || tyMin > tMax);
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    const float tzMin = ((nz ? b.y : a.z) - ray.o.z) * iz;
+    const float tzMax = ((nz ? a.z : b.y) - ray.o.z) * iz;
+    hit = hit && !(tMin > tzMax || tzMin > tMax);
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    hit = hit && (tMax > 0.0f);
+
+    const uint32_t meta = __float_as_uint(b.w);
+    const int off = __float_as_int(b.z);
+    const uint32_t count = meta & 0xffffu;
+    if (hit && count == 0) {
+      const uint32_t axis = (meta >> 16) & 0xffu;
+      const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
+      st.push(sp++, neg ? cur + 1 : off);
+      cur = neg ? off : cur + 1;
+      continue;
+    }
+    if (hit) {
+      if (!(useIgnore && off == ignore)) {
+        if (STATS) c.tris += count;    // the reference *calls* intersectTriangle primitiveCount times
+        if (intersect_triangle<PROGRAM>(sc.tris, off, ray, pl)) {
+          pl.prim = off;
+          pl.hitType = 1;
+        }
+      }
+    }
+    if (sp == 0) break;
+    cur = st.pop(--sp);
+  }
+}
+
+// ---------------------------------------------------------------- shading helpers
+__device__ __forceinline__ V3 barycentrics(float u, float v) {   // (float3)(1.0 - u - v, u, v), first in double
+  return V3{(float)((1.0 - (double)u) - (double)v), u, v};
+}
+// float3 A*w.x + B*w.y + C*w.z evaluated (A*wx + B*wy) + C*wz (acc.cl:247)
+__device__ __forceinline__ V3 bary3(const float* a, const float* b, const float* cc, V3 w) {
+  return V3{(a[0] * w.x + b[0] * w.y) + cc[0] * w.z, (a[1] * w.x + b[1] * w.y) + cc[1] * w.z,
+            (a[2] * w.x + b[2] * w.y) + cc[2] * w.z};
+}
+__device__ __forceinline__ const float* prim_ptr(const SceneDev& sc, int p) { return sc.prims + 19 * (size_t)p; }
+__device__ __forceinline__ int prim_material(const float* pr) { return __float_as_int(pr[18]); }
+
+// `primitiveIndex == lights.primitives[x]` for x < count, no hitType check (acc.cl:233-237)
+__device__ __forceinline__ bool is_light(const Lights* L, int prim) {
+  bool hit = false;
+  const uint32_t n = L->count;
+  for (uint32_t x = 0; x < n; x++) hit = hit || ((uint32_t)prim == L->primitives[x & 63u]);
+  return hit;
+}
+// int(random * count) indexes the light list; index == count reads its zero-initialised tail (Q7)
+__device__ __forceinline__ const float* light_prim(const SceneDev& sc, float rnd) {
+  const int idx = (int)(rnd * (float)sc.lights->count);
+  const uint32_t p = (idx >= 0 && idx < 64) ? sc.lights->primitives[idx] : 0u;
+  return prim_ptr(sc, (int)p);
+}
+
+// Light sample + shadow ray: acc.cl:239-279, basic_lighting.cl:234-274, gi.cl:267-297 and :323-349.
+// normal_w is 0 in accumulator/basic_lighting, 1 in GI (extractDataFromBarycentrics returns w = 1, gi.cl:238).
+template <int PROGRAM, bool DEEP, bool STATS>
+__device__ inline bool direct_light(const SceneDev& sc, const float* pr, int primIndex, float u, float v, float fx,
+                                    float fy, float seedIndex, float seedU, float seedV, float normal_w, V4& position,
+                                    V4& normal, float& ndotl, Stack<DEEP>& st, Counters& c) {
+  const V3 b = barycentrics(u, v);
+  const V3 p3 = bary3(pr + 0, pr + 3, pr + 6, b);
+  position = mk4(p3.x, p3.y, p3.z, 1.0f);
+  const V3 n3 = bary3(pr + 9, pr + 12, pr + 15, b);
+  normal = mk4(n3.x, n3.y, n3.z, normal_w);
+
+  const float* lp = light_prim(sc, random_(fx, fy, seedIndex));
+  float uvx = random_(fx, fy, seedU);
+  float uvy = random_(fx, fy, seedV);
+  if (uvx + uvy > 1.0f) {
+    uvx = 1.0f - uvx;
+    uvy = 1.0f - uvy;
+  }
+  const V3 lb = barycentrics(uvx, uvy);
+  const V3 l3 = bary3(lp + 0, lp + 3, lp + 6, lb);
+  const V4 lightPosition = mk4(l3.x, l3.y, l3.z, 1.0f);
+
+  const V4 toLight = normalize4(sub4(lightPosition, position));
+  Hit spl{0, 0, (float)((double)distance4(position, lightPosition) - 0.01), 0.0f, 0.0f};
+  const Ray shadowRay{position, toLight};
+  if (STATS) c.shadow++;
+  traverse<PROGRAM, DEEP, STATS>(sc, shadowRay, true, primIndex, spl, st, c);
+  ndotl = dot4(toLight, normal);
+  return spl.hitType == 0;
+}
+
+// basic.cl:65-71
+__device__ inline V4 refract_(V4 I, V4 N, float firstIOR, float secondIOR) {
+  const float n = firstIOR / secondIOR;
+  const float cosI = -dot4(N, I);
+  const float sinT2 = (float)((double)(n * n) * (1.0 - (double)(cosI * cosI)));
+  const float cosT = (float)sqrt(1.0 - (double)sinT2);
+  return add4(scale4(n, I), scale4(n * cosI - cosT, N));
+}
+
+// basic.cl:225-277
+template <bool DEEP, bool STATS>
+__device__ inline void trace_ray_through_lens(const SceneDev& sc, Hit& pl, Ray& ray, Stack<DEEP>& st, Counters& c) {
+  const float* pr = prim_ptr(sc, pl.prim);
+  const Material* m = sc.mats + prim_material(pr);
+  V3 b = barycentrics(pl.u, pl.v);
+  V3 p3 = bary3(pr + 0, pr + 3, pr + 6, b);
+  V4 position = mk4(p3.x, p3.y, p3.z, 1.0f);
+  V3 n3 = bary3(pr + 9, pr + 12, pr + 15, b);
+  V4 normal = mk4(n3.x, n3.y, n3.z, 0.0f);
+  V4 tdir = refract_(ray.d, normal, 1.0f, m->ior);
+
+  Hit pl2{0, 0, kFltMax, 0.0f, 0.0f};
+  const Ray ray2{position, tdir};
+  traverse<kBasic, DEEP, STATS>(sc, ray2, true, pl.prim, pl2, st, c);
+
+  pr = prim_ptr(sc, pl2.prim);
+  m = sc.mats + prim_material(pr);
+  b = barycentrics(pl2.u, pl2.v);
+  p3 = bary3(pr + 0, pr + 3, pr + 6, b);
+  position = mk4(p3.x, p3.y, p3.z, 1.0f);
+  n3 = bary3(pr + 9, pr + 12, pr + 15, b);
+  normal = mk4(n3.x, n3.y, n3.z, 0.0f);
+  tdir = refract_(tdir, neg4(normal), m->ior, 1.0f);
+
+  pl = Hit{0, 0, kFltMax, 0.0f, 0.0f};
+  ray.o = position;
+  ray.d = tdir;
+  traverse<kBasic, DEEP, STATS>(sc, ray, true, pl2.prim, pl, st, c);
+}
+
+// basic.cl:279-307
+template <bool DEEP, bool STATS>
+__device__ inline V3 shade_basic(const SceneDev& sc, Ray ray, Stack<DEEP>& st, Counters& c) {
+  V3 out{0.0f, 0.0f, 0.0f};
+  Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
+  traverse<kBasic, DEEP, STATS>(sc, ray, false, 0, pl, st, c);
+  if (pl.hitType == 1) {
+    const float* pr = prim_ptr(sc, pl.prim);
+    const Material* m = sc.mats + prim_material(pr);
+    if ((double)m->dissolve < 1.0) {
+      trace_ray_through_lens<DEEP, STATS>(sc, pl, ray, st, c);
+      if (pl.hitType == 1) {
+        pr = prim_ptr(sc, pl.prim);
+        m = sc.mats + prim_material(pr);
+      }
+    }
+    out = V3{m->diffuse[0], m->diffuse[1], m->diffuse[2]};
+  }
+  return out;
+}
+
+// acc.cl:219-282 / basic_lighting.cl:220-277
+template <int PROGRAM, bool DEEP, bool STATS>
+__device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, float fx, float fy, uint32_t s,
+                                    Stack<DEEP>& st, Counters& c) {
+  V3 out{0.0f, 0.0f, 0.0f};
+  Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
+  traverse<PROGRAM, DEEP, STATS>(sc, cameraRay, false, 0, pl, st, c);
+  if (PROGRAM == kAccumulator) {
+    if (is_light(sc.lights, pl.prim)) return V3{1.0f, 1.0f, 1.0f};
+  }
+  if (pl.hitType == 1) {
+    const float* pr = prim_ptr(sc, pl.prim);
+    const Material* m = sc.mats + prim_material(pr);
+    V4 position, normal;
+    float ndotl;
+    if (direct_light<PROGRAM, DEEP, STATS>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u),
+                                           0.0f, position, normal, ndotl, st, c)) {
+      out = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
+    }
+  }
+  return out;
+}
+
+// gi.cl:68-74
+__device__ inline V4 uniform_sample_hemisphere(float uvx, float uvy) {
+  const float z = uvx;
+  const float r = __builtin_sqrtf(__builtin_fmaxf(0.0f, 1.0f - z * z));
+  const float phi = (float)(2.0 * M_PI * (double)uvy);
+  return mk4(r * cosf_portable(phi), z, r * sinf_portable(phi), 0.0f);
+}
+// gi.cl:76-81
+__device__ inline V4 align_hemisphere(V4 h, V4 up) {
+  const V4 right = normalize4(cross4(up, mk4(0.0072f, 1.0f, 0.0034f, 0.0f)));
+  const V4 forward = cross4(right, up);
+  return add4(add4(scale4(h.x, right), scale4(h.y, up)), scale4(h.z, forward));
+}
+
+// gi.cl:241-375
+template <bool DEEP, bool STATS>
+__device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx, float fy, uint32_t s, int maxDepth,
+                              Stack<DEEP>& st, Counters& c) {
+  V3 direct{0.0f, 0.0f, 0.0f}, indirect{0.0f, 0.0f, 0.0f};
+  Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
+  traverse<kGI, DEEP, STATS>(sc, cameraRay, false, 0, pl, st, c);
+  if (is_light(sc.lights, pl.prim)) {
+    direct = V3{1.0f, 1.0f, 1.0f};
+  } else if (pl.hitType == 1) {
+    const float* pr = prim_ptr(sc, pl.prim);
+    const Material* m = sc.mats + prim_material(pr);
+    V4 position, normal;
+    float ndotl;
+    if (direct_light<kGI, DEEP, STATS>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u), 1.0f,
+                                       position, normal, ndotl, st, c)) {
+      direct = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
+    }
+    V4 hemi = uniform_sample_hemisphere(random_(fx, fy, (float)(s + 3u)), random_(fx, fy, (float)(s + 4u)));
+    Ray ext{position, align_hemisphere(hemi, normal)};
+    V4 previousNormal = normal;
+    int previousPrimitive = pl.prim;
+    bool rayActive = true;
+    for (int d = 0; d < maxDepth && rayActive; d++) {
+      Hit epl{0, 0, kFltMax, 0.0f, 0.0f};
+      traverse<kGI, DEEP, STATS>(sc, ext, true, previousPrimitive, epl, st, c);
+      const float w = (float)(1.0 / (double)(d + 1));
+      const uint32_t sd = s + (uint32_t)d;
+      if (is_light(sc.lights, epl.prim)) {
+        // hit a light: add and keep looping with the SAME ray (gi.cl:319-321)
+        const float k = dot4(previousNormal, ext.d);
+        indirect.x += (w * 1.0f) * k;
+        indirect.y += (w * 1.0f) * k;
+        indirect.z += (w * 1.0f) * k;
+      } else if (epl.hitType == 1) {
+        const float* epr = prim_ptr(sc, epl.prim);
+        const Material* em = sc.mats + prim_material(epr);
+        V4 epos, enorm;
+        float endotl;
+        if (direct_light<kGI, DEEP, STATS>(sc, epr, epl.prim, epl.u, epl.v, fx, fy, (float)(sd + 5u), (float)(sd + 6u),
+                                           (float)(sd + 7u), 1.0f, epos, enorm, endotl, st, c)) {
+          indirect.x += (w * em->diffuse[0]) * endotl;
+          indirect.y += (w * em->diffuse[1]) * endotl;
+          indirect.z += (w * em->diffuse[2]) * endotl;
+          hemi = uniform_sample_hemisphere(random_(fx, fy, (float)(sd + 8u)), random_(fx, fy, (float)(sd + 9u)));
+          ext.o = epos;
+          ext.d = align_hemisphere(hemi, enorm);
+          previousNormal = enorm;
+          previousPrimitive = epl.prim;
+        } else {
+          rayActive = false;
+        }
+      } else {
+        rayActive = false;
+      }
+    }
+  }
+  return V3{direct.x + indirect.x, direct.y + indirect.y, direct.z + indirect.z};
+}
+
+// Per-frame uniforms.  cos/sin(yaw) are evaluated once on the host as (float)cos((double)yaw): the
+// reference evaluates cos(camera->yaw) per work-item (acc.cl:309-310), a uniform.
+struct FrameParams {
+  float camx, camy, camz;
+  float cosYaw, sinYaw;
+  uint32_t frameCount;
+  uint32_t width, height, depth;
+  int32_t clampOutput;      // linearKernel of the lighting programs clamps, tileKernel does not (acc.cl:316-318/:356-358)
+  int32_t giMaxDepth;
+  int32_t accumulateN;      // < 0: overwrite; >= 0: running mean with n = accumulateN (accumulator.frag:10-20)
+  // tile sharding (lenstrace_hip.h): tiles tile_first + k*tile_stride, k < tilesInCall
+  uint32_t tileW, tileH, tilesX, tileFirst, tileStride, tilesInCall;
+  uint32_t blocksPerTileX, blocksPerTile;   // 16x16-pixel workgroup tiles per image tile
+};
+
+// Camera ray of pixel (x,y): acc.cl:304-312.
+__device__ __forceinline__ Ray camera_ray(const FrameParams& fp, int x, int y, float& fx, float& fy) {
+  const V4 cameraPosition = mk4(fp.camx, fp.camy, fp.camz, 1.0f);
+  const V4 film = mk4(((float)x / (float)fp.width) - 0.5f, ((float)y / (float)fp.height) - 0.5f, 0.0f, 1.0f);
+  const V4 aperture = mk4(0.0f, 0.0f, 5.0f, 1.0f);
+  Ray ray{add4(cameraPosition, film), sub4(aperture, film)};
+  const float newX = (fp.cosYaw * ray.d.x) + (fp.sinYaw * ray.d.z);
+  const float newZ = (-fp.sinYaw * ray.d.x) + (fp.cosYaw * ray.d.z);
+  ray.d.x = newX;
+  ray.d.z = newZ;
+  fx = film.x;
+  fy = film.y;
+  return ray;
+}
+
+// The body of linearKernel / tileKernel for one pixel, all five programs
+// (acc.cl:314-318, basic.cl:338-342, basic_lighting.cl:309-321, resources gi :408-420).
+template <int PROGRAM, bool DEEP, bool STATS>
+__device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int x, int y, Stack<DEEP>& st, Counters& c) {
+  float fx, fy;
+  const Ray ray = camera_ray(fp, x, y, fx, fy);
+  V3 color;
+  if (PROGRAM == kBasic) {
+    color = shade_basic<DEEP, STATS>(sc, ray, st, c);
+  } else if (PROGRAM == kAccumulator) {
+    color = shade_lighting<kAccumulator, DEEP, STATS>(sc, ray, fx, fy, fp.frameCount, st, c);
+  } else if (PROGRAM == kGI) {
+    color = shade_gi<DEEP, STATS>(sc, ray, fx, fy, fp.frameCount, fp.giMaxDepth, st, c);
+  } else {
+    const uint32_t base = fp.frameCount * 32u;
+    for (int k = 0; k < 25; k++) {
+      const V3 cn = (PROGRAM == kBasicLighting)
+                        ? shade_lighting<kBasicLighting, DEEP, STATS>(sc, ray, fx, fy, base + (uint32_t)k, st, c)
+                        : shade_gi<DEEP, STATS>(sc, ray, fx, fy, base + (uint32_t)k, fp.giMaxDepth, st, c);
+      if (k == 0) {
+        color = cn;
+      } else {
+        const float a = ((float)(25 - k)) / (float)25;
+        color = V3{((1.0f - a) * color.x) + (a * cn.x), ((1.0f - a) * color.y) + (a * cn.y),
+                   ((1.0f - a) * color.z) + (a * cn.z)};
+      }
+    }
+  }
+  if (PROGRAM != kBasic && fp.clampOutput) color = V3{clamp01(color.x), clamp01(color.y), clamp01(color.z)};
+  return color;
+}
+
+}  // namespace lt

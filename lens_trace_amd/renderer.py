@@ -1,0 +1,134 @@
+"""Python mirror of the renderer plugin surface for this path
+(/root/reference/include/lens_trace/renderer.h:5-9, structures.h:51-79, src/opencl/renderer_opencl.cpp:56-153):
+RendererHIP.render(RenderPropertiesHIP) fills a caller-owned float buffer, synchronously.  Everything goes
+through the C ABI of liblenstrace-hip.so; there is no other compute path."""
+import ctypes
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import _capi as C
+from .scene import Scene
+
+KERNEL_MODE_LINEAR, KERNEL_MODE_TILE = C.KERNEL_MODE_LINEAR, C.KERNEL_MODE_TILE
+THREAD_ORGANIZATION_MODE_MAX_FIT, THREAD_ORGANIZATION_MODE_CUSTOM = 0, 1
+
+
+@dataclass
+class ThreadOrganizationHIP:
+    """Accepted for API parity with ThreadOrganizationCUDA (structures.h:45-49); pixels never depend on the
+    launch decomposition (the reference's CustomBlockSize test), and this backend picks its own."""
+    blockSize: tuple = (0, 0)
+
+
+@dataclass
+class RenderPropertiesHIP:
+    kernelFilePath: str
+    imageDimensions: tuple                       # (W, H, depth)
+    pOutputBuffer: np.ndarray                    # float32, >= W*H*depth elements, caller-owned
+    pAccelerationStructureExplicit: Scene        # provides node / primitive / light buffers
+    pModel: Optional[Scene] = None               # provides the material buffer (defaults to the same Scene)
+    pCamera: bytes = b""                         # 28-byte camera buffer
+    kernelMode: int = KERNEL_MODE_LINEAR
+    threadOrganizationMode: int = THREAD_ORGANIZATION_MODE_MAX_FIT
+    threadOrganization: ThreadOrganizationHIP = field(default_factory=ThreadOrganizationHIP)
+    # extensions (the reference's unused pNext slot): progressive rendering on the device
+    frameFirst: int = 0
+    frameCount: int = 0
+    accumulate: bool = False
+    accumulateBase: int = 0
+    giMaxDepth: int = 0
+    collectStats: bool = False
+
+
+def make_desc(program, W, H, depth, camera28, kernel_mode=KERNEL_MODE_LINEAR, frame_first=0, frame_count=0,
+              accumulate=False, accumulate_base=0, tile=None, gi_max_depth=0, stats=False):
+    d = C.RenderDesc()
+    d.struct_size = ctypes.sizeof(C.RenderDesc)
+    d.program, d.kernel_mode = program, kernel_mode
+    d.width, d.height, d.depth = W, H, depth
+    cam = bytes(camera28)
+    if len(cam) != 28:
+        raise ValueError("camera buffer must be 28 bytes")
+    ctypes.memmove(d.camera, cam, 28)
+    d.frame_first, d.frame_count = frame_first, frame_count
+    d.accumulate, d.accumulate_base = int(bool(accumulate)), accumulate_base
+    if tile is not None:
+        d.tile_w, d.tile_h, d.tile_first, d.tile_stride = tile
+    d.gi_max_depth = gi_max_depth
+    d.flags = C.RENDER_FLAG_STATS if stats else 0
+    return d
+
+
+class RendererHIP:
+    """One context per GPU.  `device` is the HIP ordinal."""
+
+    def __init__(self, device=0):
+        self._L = C.load()
+        self._ctx = ctypes.c_void_p()
+        rc = self._L.lt_hip_create(device, ctypes.byref(self._ctx))
+        if rc:
+            raise C.LensTraceError(rc, self._L.lt_hip_last_error(None).decode())
+        self._scene_key = None
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.lt_hip_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise C.LensTraceError(rc, self._L.lt_hip_last_error(self._ctx).decode())
+
+    # -- scene -------------------------------------------------------------------------------------
+    def set_scene(self, scene: Scene, materials: Optional[Scene] = None):
+        m = (materials or scene).materials
+        arrs = [np.ascontiguousarray(a) for a in (scene.nodes, scene.prims, m, scene.lights)]
+        args = []
+        for a in arrs:
+            args += [a.ctypes.data_as(ctypes.c_void_p), a.nbytes]
+        self._check(self._L.lt_hip_set_scene(self._ctx, *args))
+        self._scene_key = (id(scene), id(materials or scene))
+
+    # -- the plugin entry point ----------------------------------------------------------------------
+    def render(self, props: RenderPropertiesHIP):
+        W, H, D = props.imageDimensions
+        out = props.pOutputBuffer
+        if out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError("pOutputBuffer must be contiguous float32")
+        key = (id(props.pAccelerationStructureExplicit), id(props.pModel or props.pAccelerationStructureExplicit))
+        if key != self._scene_key:      # the reference re-uploads on every call; here it is cached by identity
+            self.set_scene(props.pAccelerationStructureExplicit, props.pModel)
+        program = C.program_from_path(props.kernelFilePath)
+        d = make_desc(program, W, H, D, props.pCamera, props.kernelMode, props.frameFirst, props.frameCount,
+                      props.accumulate, props.accumulateBase, None, props.giMaxDepth, props.collectStats)
+        self._check(self._L.lt_hip_render(self._ctx, ctypes.byref(d), out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+
+    # -- device-resident variants (bench / multi-GPU) -----------------------------------------------------
+    def output_floats(self, desc):
+        n = ctypes.c_uint64(0)
+        self._check(self._L.lt_hip_output_floats(ctypes.byref(desc), ctypes.byref(n)))
+        return n.value
+
+    def render_device(self, desc, out_ptr, out_bytes, stream=0):
+        self._check(self._L.lt_hip_render_device(self._ctx, ctypes.byref(desc), ctypes.c_void_p(out_ptr), out_bytes,
+                                                 ctypes.c_void_p(stream)))
+
+    def untile(self, gathered_ptr, floats_per_rank, n_ranks, W, H, D, tile_w, tile_h, image_ptr, stream=0):
+        self._check(self._L.lt_hip_untile(self._ctx, ctypes.c_void_p(gathered_ptr), floats_per_rank, n_ranks, W, H, D,
+                                          tile_w, tile_h, ctypes.c_void_p(image_ptr), ctypes.c_void_p(stream)))
+
+    def synchronize(self, stream=0):
+        self._check(self._L.lt_hip_synchronize(self._ctx, ctypes.c_void_p(stream)))
+
+    def stats(self):
+        s = C.Stats()
+        self._check(self._L.lt_hip_get_stats(self._ctx, ctypes.byref(s)))
+        return s.as_dict()

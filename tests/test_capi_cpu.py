@@ -1,0 +1,59 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/lenstrace_hip.h declares, and
+its GPU-free entry points behave.  No compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from lens_trace_amd import _capi as C
+from lens_trace_amd.renderer import make_desc
+from lens_trace_amd.scene import camera_bytes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.load()
+    header = open(os.path.join(ROOT, "include", "lenstrace_hip.h")).read()
+    declared = set(re.findall(r"\b(lt_hip_[a-z_]+)\s*\(", header)) - {"lt_hip_render_desc"}
+    assert declared == set(C.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.lt_hip_abi_version() == 1
+
+
+@pytest.mark.parametrize("path,prog", [
+    ("resources/kernels/opencl/basic.cl", C.PROGRAM_BASIC),
+    ("resources/kernels/opencl/basic_lighting.cl", C.PROGRAM_BASIC_LIGHTING),
+    ("examples/accumulator/resources/kernels/accumulator.cl", C.PROGRAM_ACCUMULATOR),
+    ("resources/kernels/accumulator.cl", C.PROGRAM_ACCUMULATOR),
+    ("examples/global_illumination/resources/kernels/global_illumination.cl", C.PROGRAM_GLOBAL_ILLUMINATION),
+    ("resources/kernels/global_illumination.cl", C.PROGRAM_GLOBAL_ILLUMINATION),
+    ("resources/kernels/opencl/global_illumination.cl", C.PROGRAM_GLOBAL_ILLUMINATION_25),
+    ("basic", C.PROGRAM_BASIC),
+])
+def test_program_from_path(path, prog):
+    assert C.program_from_path(path) == prog
+
+
+def test_unknown_program_is_an_error():
+    with pytest.raises(C.LensTraceError):
+        C.program_from_path("examples/custom_kernel/resources/kernels/custom_opencl.cl")
+
+
+def test_output_floats_and_desc_validation():
+    L = C.load()
+    cam = camera_bytes(0, 2.5, -50)
+    n = ctypes.c_uint64()
+    d = make_desc(C.PROGRAM_BASIC, 100, 100, 3, cam)
+    assert L.lt_hip_output_floats(ctypes.byref(d), ctypes.byref(n)) == 0 and n.value == 30000
+    # 3840x2160 in 64x64 tiles = 60 x 34 tiles (last row clipped); rank 3 of 8 takes tiles 3, 11, ...
+    d = make_desc(C.PROGRAM_ACCUMULATOR, 3840, 2160, 3, cam, tile=(64, 64, 3, 8))
+    assert L.lt_hip_output_floats(ctypes.byref(d), ctypes.byref(n)) == 0
+    assert n.value == len(range(3, 60 * 34, 8)) * 64 * 64 * 3
+    d = make_desc(C.PROGRAM_BASIC, 0, 100, 3, cam)
+    assert L.lt_hip_output_floats(ctypes.byref(d), ctypes.byref(n)) == C.LT_ERR_INVALID_ARGUMENT
+    d = make_desc(C.PROGRAM_BASIC, 100, 100, 3, cam)
+    d.struct_size = 8
+    assert L.lt_hip_output_floats(ctypes.byref(d), ctypes.byref(n)) == C.LT_ERR_INVALID_ARGUMENT
