@@ -77,7 +77,9 @@ enum {
 enum { LT_KERNEL_MODE_LINEAR = 0, LT_KERNEL_MODE_TILE = 1 };
 
 enum {
-  LT_RENDER_FLAG_STATS = 1u     /* count rays / node visits / triangle tests with device atomics (slower) */
+  LT_RENDER_FLAG_STATS = 1u,    /* count rays / node visits / triangle tests with device atomics (slower) */
+  LT_RENDER_FLAG_PIXEL_COUNTERS = 2u /* diagnostic (implies STATS, needs depth >= 4): instead of the colour, write each
+                                        pixel's own {rays, shadow rays, node visits, triangle tests} as 4 floats */
 };
 
 typedef struct lt_hip_render_desc {

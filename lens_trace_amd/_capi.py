@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblenstrace-hip.so")
+LIB_PATH = os.environ.get("LT_HIP_LIBRARY") or os.path.join(_HERE, "lib", "liblenstrace-hip.so")
 
 (LT_OK, LT_ERR_INVALID_ARGUMENT, LT_ERR_NO_DEVICE, LT_ERR_HIP, LT_ERR_NO_SCENE, LT_ERR_BAD_SCENE,
  LT_ERR_BUFFER_TOO_SMALL, LT_ERR_UNKNOWN_PROGRAM) = range(8)
@@ -14,6 +14,7 @@ STATUS_NAMES = ["LT_OK", "LT_ERR_INVALID_ARGUMENT", "LT_ERR_NO_DEVICE", "LT_ERR_
 PROGRAM_BASIC, PROGRAM_BASIC_LIGHTING, PROGRAM_ACCUMULATOR, PROGRAM_GLOBAL_ILLUMINATION, PROGRAM_GLOBAL_ILLUMINATION_25 = range(5)
 KERNEL_MODE_LINEAR, KERNEL_MODE_TILE = 0, 1
 RENDER_FLAG_STATS = 1
+RENDER_FLAG_PIXEL_COUNTERS = 2
 
 # every symbol include/lenstrace_hip.h declares
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",
@@ -56,6 +57,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as the
+    # system one).  Importing torch first makes this library bind to the copy torch uses, so device pointers,
+    # streams and RCCL buffers are shared; loaded the other way round, the process ends up with two runtimes
+    # and torch reports "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: the HIP extension is not built (run __graft_entry__.build()); "
                           "there is no CPU fallback" % LIB_PATH)

@@ -43,7 +43,9 @@ __global__ __launch_bounds__(kBlock) void lt_render_kernel(SceneDev sc, FramePar
   if (valid) {
     const V3 color = shade_pixel<PROGRAM, DEEP, STATS>(sc, fp, (int)x, (int)y, st, c);
     float* o = out + (((size_t)k * fp.tileH + ly) * fp.tileW + lx) * fp.depth;
-    if (fp.accumulateN <= 0) {   // overwrite, or first frame of a running mean (`if (frameCount > 0)` guard)
+    if (STATS && fp.pixelCounters) {
+      o[0] = (float)c.rays; o[1] = (float)c.shadow; o[2] = (float)c.nodes; o[3] = (float)c.tris;
+    } else if (fp.accumulateN <= 0) {   // overwrite, or first frame of a running mean (`if (frameCount > 0)` guard)
       o[0] = color.x; o[1] = color.y; o[2] = color.z;
     } else {                     // accumulator.frag:12-18: (c + acc*n) / (n+1)
       const float n = (float)fp.accumulateN, n1 = (float)(fp.accumulateN + 1);
@@ -352,6 +354,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
 
   FrameParams fp{};
   fp.camx = cam[0]; fp.camy = cam[1]; fp.camz = cam[2];
+  fp.apx = 0.0f; fp.apy = 0.0f; fp.apz = 5.0f;
   fp.cosYaw = (float)std::cos((double)cam[3]);
   fp.sinYaw = (float)std::sin((double)cam[3]);
   fp.width = d->width; fp.height = d->height; fp.depth = d->depth;
@@ -361,7 +364,10 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   fp.tilesInCall = p.tilesInCall;
   fp.blocksPerTileX = p.bptx; fp.blocksPerTile = p.bptx * p.bpty;
 
-  const bool stats = (d->flags & LT_RENDER_FLAG_STATS) != 0;
+  const bool pixelCounters = (d->flags & LT_RENDER_FLAG_PIXEL_COUNTERS) != 0;
+  if (pixelCounters && d->depth < 4) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "LT_RENDER_FLAG_PIXEL_COUNTERS needs depth >= 4");
+  fp.pixelCounters = pixelCounters;
+  const bool stats = pixelCounters || (d->flags & LT_RENDER_FLAG_STATS) != 0;
   const bool deep = ctx->bvh_height > kLdsStack;
   const uint32_t frames = d->frame_count ? d->frame_count : 1;
   const uint64_t nblocks = (uint64_t)p.tilesInCall * fp.blocksPerTile;

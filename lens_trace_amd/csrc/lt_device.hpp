@@ -434,11 +434,16 @@ __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx
 // reference evaluates cos(camera->yaw) per work-item (acc.cl:309-310), a uniform.
 struct FrameParams {
   float camx, camy, camz;
+  // aperaturePosition (0, 0, 5) of acc.cl:306, passed as run-time values on purpose: with a literal 0 the
+  // compiler folds `0.0f - film` into a negate source modifier on the consumers (1/d), which turns the +0
+  // direction component of the image-centre column/row into -0 and flips dirIsNeg there.
+  float apx, apy, apz;
   float cosYaw, sinYaw;
   uint32_t frameCount;
   uint32_t width, height, depth;
   int32_t clampOutput;      // linearKernel of the lighting programs clamps, tileKernel does not (acc.cl:316-318/:356-358)
   int32_t giMaxDepth;
+  int32_t pixelCounters;    // diagnostic: write the pixel's work counters instead of its colour
   int32_t accumulateN;      // < 0: overwrite; >= 0: running mean with n = accumulateN (accumulator.frag:10-20)
   // tile sharding (lenstrace_hip.h): tiles tile_first + k*tile_stride, k < tilesInCall
   uint32_t tileW, tileH, tilesX, tileFirst, tileStride, tilesInCall;
@@ -449,7 +454,7 @@ struct FrameParams {
 __device__ __forceinline__ Ray camera_ray(const FrameParams& fp, int x, int y, float& fx, float& fy) {
   const V4 cameraPosition = mk4(fp.camx, fp.camy, fp.camz, 1.0f);
   const V4 film = mk4(((float)x / (float)fp.width) - 0.5f, ((float)y / (float)fp.height) - 0.5f, 0.0f, 1.0f);
-  const V4 aperture = mk4(0.0f, 0.0f, 5.0f, 1.0f);
+  const V4 aperture = mk4(fp.apx, fp.apy, fp.apz, 1.0f);
   Ray ray{add4(cameraPosition, film), sub4(aperture, film)};
   const float newX = (fp.cosYaw * ray.d.x) + (fp.sinYaw * ray.d.z);
   const float newZ = (-fp.sinYaw * ray.d.x) + (fp.cosYaw * ray.d.z);

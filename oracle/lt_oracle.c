@@ -588,6 +588,29 @@ int lt_oracle_render(int program, int mode, const void* nodes, const void* prims
   return c.error;
 }
 
+/* Per-pixel work counters for debugging / heat maps: counts[(y*W+x)*4 + {0,1,2,3}] =
+ * {rays, shadow rays, node visits, triangle tests} of that pixel. */
+int lt_oracle_pixel_counters(int program, int mode, const void* nodes, const void* prims, const void* mats,
+                             const void* lights, const void* camera28, uint32_t W, uint32_t H, int gi_max_depth,
+                             uint32_t* counts) {
+  Ctx c;
+  ctx_init(&c, nodes, prims, mats, lights, gi_max_depth);
+  Cam cam;
+  memcpy(&cam, camera28, sizeof(cam));
+  for (uint32_t y = 0; y < H; y++)
+    for (uint32_t x = 0; x < W; x++) {
+      float rgb[3];
+      lt_oracle_stats before = c.st;
+      pixel(&c, program, mode, &cam, (int)x, (int)y, W, H, rgb);
+      uint32_t* o = counts + ((size_t)y * W + x) * 4;
+      o[0] = (uint32_t)(c.st.rays - before.rays);
+      o[1] = (uint32_t)(c.st.shadow_rays - before.shadow_rays);
+      o[2] = (uint32_t)(c.st.node_visits - before.node_visits);
+      o[3] = (uint32_t)(c.st.tri_tests - before.tri_tests);
+    }
+  return c.error;
+}
+
 /* The OpenCL backend's launch decomposition, restated (renderer_opencl.cpp:80-146 and
  * the index arithmetic of linearKernel / tileKernel, accumulator.cl:296-302 / :333-342):
  * workBlockCount = (W / gsx) * (H / gsy) launches of global size (gsx,gsy); tileKernel

@@ -44,6 +44,8 @@ def lib():
         L.lt_oracle_render_opencl_launch.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, i32,
                                                      ctypes.POINTER(Stats)]
         L.lt_oracle_render_opencl_launch.restype = i32
+        L.lt_oracle_pixel_counters.argtypes = [i32, i32, vp, vp, vp, vp, vp, u32, u32, i32, vp]
+        L.lt_oracle_pixel_counters.restype = i32
         L.lt_oracle_accumulate.argtypes = [vp, vp, ctypes.c_uint64, u32]
         L.lt_oracle_accumulate.restype = None
         L.lt_oracle_random.argtypes = [ctypes.c_float] * 3
@@ -112,6 +114,17 @@ def render_opencl_launch(scene, camera28, W, H, program, mode, global_size, loca
                                           ctypes.byref(st))
     if rc:
         raise RuntimeError("oracle launch error %d" % rc)
+    return out
+
+
+def pixel_counters(scene, camera28, W, H, program, mode=MODE_LINEAR, gi_max_depth=16):
+    """uint32 [H,W,4] = rays, shadow rays, node visits, triangle tests per pixel."""
+    L = lib()
+    n, p, m, l = _scene_arrays(scene)
+    cam = np.frombuffer(bytes(camera28), dtype=np.uint8).copy()
+    out = np.zeros((H, W, 4), dtype=np.uint32)
+    if L.lt_oracle_pixel_counters(program, mode, _p(n), _p(p), _p(m), _p(l), _p(cam), W, H, gi_max_depth, _p(out)):
+        raise RuntimeError("oracle: traversal stack overflow")
     return out
 
 
