@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement of BASELINE.json: Mrays/s (primary + secondary + shadow) and frame ms on a
+synthetic 1M-triangle scene at 3840x2160, 16 samples per pixel (`accumulator` program, frameCount 1..16, device-side
+running mean), image-tile-split over N GPUs of one node (one process per GPU) with ONE gather of tile pixels to
+rank 0 per frame.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one complete frame of the workload: all 16 sample launches of this rank's tiles, the gather (N > 1)
+and the root-side untile.  Timed region: barrier + synchronize, K steps, synchronize + barrier; MAX over ranks.
+Scene and framebuffers are resident in HBM before the timed region starts.  Rank 0 prints one JSON line.
+
+`roofline` prices the dominant kernel (one sample launch of lt_render_kernel) against HBM: achieved = ALGORITHMIC
+bytes per launch / average launch duration (HIP events on the launch stream, taken inside the timed region);
+algorithmic bytes = 32 B x node visits + 76 B x triangle tests + 36 B x pixels (12 B written + 24 B running-mean
+read-modify-write), SURVEY.md section 8(d) -- node visits / triangle tests are the reference algorithm's counts,
+measured once with device atomics (and equal to the CPU oracle's counters, see tests).
+`cpu_baseline` is the CPU oracle (a C restatement of the reference kernels, kind "port") on this host's cores over
+one bounded sample of the same workload; it is a reported baseline, not a target."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--cells", type=int, default=708, help="height-field cells per side (708 -> 1 002 530 triangles)")
+    ap.add_argument("--scene", default="wall", choices=["wall", "soup", "blob", "cornell"])
+    ap.add_argument("--program", default="accumulator")
+    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of one 4K frame for the CPU baseline sample (0 = auto, ~10-30 s)")
+    return ap.parse_args()
+
+
+def build_scene(args):
+    from lens_trace_amd import scene as sc
+    from lens_trace_amd import synth
+    if args.scene == "wall":
+        return synth.heightfield_wall(args.cells), "synthetic height-field wall"
+    if args.scene == "soup":
+        return synth.triangle_soup(2 * args.cells * args.cells), "synthetic triangle soup (seed 1)"
+    if args.scene == "blob":
+        return synth.blob_in_box(), "synthetic blob in a box"
+    return sc.load_ltsb(os.path.join(ROOT, "tests", "golden", "cornell_box_O0.ltsb")), "Cornell box (reference buffers)"
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from lens_trace_amd import _capi as C
+    from lens_trace_amd.renderer import RendererHIP, make_desc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    scene, scene_name = build_scene(args)
+    scene.validate()
+    W, H, D = args.width, args.height, 3
+    program = C.program_from_path(args.program)
+    r = RendererHIP(local_rank)
+    r.set_scene(scene)
+
+    tile = (args.tile, args.tile, rank, world) if world > 1 else None
+
+    def desc(stats=False):
+        return make_desc(program, W, H, D, scene.camera, frame_first=1, frame_count=args.spp, accumulate=True, accumulate_base=0,
+                         tile=tile, stats=stats)
+
+    d = desc()
+    my_floats = r.output_floats(d)
+    # every rank's stack is padded to the largest one so that the gather is uniform
+    tiles_x, tiles_y = (W + args.tile - 1) // args.tile, (H + args.tile - 1) // args.tile
+    per_rank = my_floats if world == 1 else ((tiles_x * tiles_y + world - 1) // world) * args.tile * args.tile * D
+    mine = torch.zeros(per_rank, dtype=torch.float32, device=dev)
+    gathered = [torch.empty(per_rank, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stack = torch.empty((world, per_rank), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    image = torch.empty((H, W, D), dtype=torch.float32, device=dev) if rank == 0 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(dd):
+        r.render_device(dd, mine.data_ptr(), per_rank * 4, stream)
+        if world > 1:
+            dist.gather(mine, gathered, dst=0)
+            if rank == 0:
+                torch.stack(gathered, out=stack)
+                r.untile(stack.data_ptr(), per_rank, world, W, H, D, args.tile, args.tile, image.data_ptr(), stream)
+
+    # ---- reference-algorithm work counts of this rank's share (one untimed pass with device atomics) ----
+    step(desc(stats=True))
+    torch.cuda.synchronize()
+    st = r.stats()
+    counts = torch.tensor([st["rays"], st["shadow_rays"], st["node_visits"], st["tri_tests"], st["pixels"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts)
+    rays_total, shadow_total, nodes_total, tris_total, pixels_total = [float(x) for x in counts.tolist()]
+    my_alg_bytes_per_launch = (32.0 * st["node_visits"] + 76.0 * st["tri_tests"]) / args.spp + 36.0 * st["pixels"]
+
+    for _ in range(args.warmup):
+        step(d)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    launches = 0
+    for _ in range(args.steps):
+        step(d)
+        # the per-call HIP events sit on the launch stream; reading them waits for this step's kernels only
+        s = r.stats()
+        kernel_ms += s["kernel_ms"]
+        launches += s["kernel_launches"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed, kernel_ms / 1e3], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kernel_s = [float(x) for x in t.tolist()]
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        mrays = rays_total * args.steps / elapsed / 1e6
+        launch_ms = kernel_ms / max(launches, 1)
+        achieved = my_alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s (primary+secondary+shadow), 1M-tri @4K",
+            "value": round(mrays, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s, %d triangles, %dx%d, %d spp running mean, program %s, %s" % (
+                           scene_name, scene.n_prims, W, H, args.spp, args.program,
+                           "whole image on 1 GPU" if world == 1 else "%dx%d tiles interleaved over %d GPUs + 1 RCCL gather" % (args.tile, args.tile, world)),
+                       "triangles": scene.n_prims, "bvh_nodes": scene.n_nodes, "width": W, "height": H, "spp": args.spp,
+                       "rays_per_frame": rays_total, "node_visits_per_ray": nodes_total / rays_total,
+                       "tri_tests_per_ray": tris_total / rays_total, "kernel_only_mrays_per_s": round(rays_total * args.steps / kernel_s / 1e6, 2),
+                       "frame_ms": round(ms_per_step, 3)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "lt_render_kernel<accumulator>", "launch_ms": round(launch_ms, 4),
+                         "algorithmic_bytes_per_launch": my_alg_bytes_per_launch},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, scene, program)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+def cpu_baseline(args, scene, program):
+    """The CPU oracle on this host's cores, over a bounded sample of the same workload: rows of frame 1."""
+    from lens_trace_amd import scene as sc
+    from oracle import pyoracle as po
+    cores = len(os.sched_getaffinity(0))
+    W, H = args.width, args.height
+    cam = sc.camera_with_frame(scene.camera, 1)
+    band = args.cpu_rows
+    if band <= 0:
+        # calibrate on 8 rows, then size the sample for ~15 s
+        t0 = time.perf_counter()
+        _, st = po.render(scene, cam, W, H, program, threads=cores, rows=(H // 2, H // 2 + 8), want_stats=True)
+        dt = max(time.perf_counter() - t0, 1e-3)
+        band = int(max(8, min(H, 8 * 15.0 / dt)))
+    y0 = max(0, (H - band) // 2)
+    t0 = time.perf_counter()
+    _, st = po.render(scene, cam, W, H, program, threads=cores, rows=(y0, y0 + band), want_stats=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(st["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "rows %d..%d of frame 1 (%dx%d, %d rays) in %.1f s" % (y0, y0 + band, W, H, st["rays"], dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -41,7 +41,7 @@ struct RenderPropertiesHIP {
   void* pCamera;
 };
 
-class RendererHIP : public Renderer {
+class RendererHIP final : public Renderer {
  public:
   RendererHIP();                // first GPU; RendererHIP(int) picks a HIP ordinal
   explicit RendererHIP(int deviceIndex);

@@ -116,3 +116,72 @@ def save_ltsb(path, scene):
         f.write(struct.pack("<5Q", scene.nodes.size, scene.prims.size, scene.materials.size, scene.lights.size, cam.size))
         for a in (scene.nodes, scene.prims, scene.materials, scene.lights, cam):
             f.write(a.tobytes())
+
+
+# ---- scene construction through the host library (liblenstrace.so: own .obj reader + deterministic BVH builder) ----
+_host = None
+
+
+def _host_lib():
+    global _host
+    if _host is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "liblenstrace.so")
+        if not os.path.exists(path):
+            raise ImportError("%s is missing: run __graft_entry__.build()" % path)
+        from . import _capi
+        _capi.load()          # liblenstrace.so links liblenstrace-hip.so; load it (and torch's HIP runtime) first
+        L = ctypes.CDLL(path)
+        vp, u64 = ctypes.c_void_p, ctypes.c_uint64
+        L.lt_host_scene_from_obj.argtypes = [ctypes.c_char_p]
+        L.lt_host_scene_from_obj.restype = vp
+        L.lt_host_scene_from_triangles.argtypes = [vp, vp, vp, u64, vp, u64]
+        L.lt_host_scene_from_triangles.restype = vp
+        L.lt_host_scene_buffer.argtypes = [vp, ctypes.c_int, ctypes.POINTER(u64)]
+        L.lt_host_scene_buffer.restype = vp
+        L.lt_host_scene_height.argtypes = [vp]
+        L.lt_host_scene_height.restype = ctypes.c_int
+        L.lt_host_scene_free.argtypes = [vp]
+        L.lt_host_scene_free.restype = None
+        _host = L
+    return _host
+
+
+def _scene_from_handle(L, h, camera):
+    import ctypes
+    if not h:
+        raise ValueError("scene construction failed (see the message printed by Model::checkError)")
+    try:
+        bufs = []
+        for which in range(4):
+            n = ctypes.c_uint64(0)
+            p = L.lt_host_scene_buffer(h, which, ctypes.byref(n))
+            bufs.append(np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value,)).copy())
+        s = Scene(bufs[0], bufs[1], bufs[2], bufs[3], camera or camera_bytes(0.0, 2.5, -50.0))
+        s.height = L.lt_host_scene_height(h)
+        return s
+    finally:
+        L.lt_host_scene_free(h)
+
+
+def load_obj(path, camera=None):
+    """Model(path) + AccelerationStructureExplicit, in this repository's own implementation."""
+    L = _host_lib()
+    return _scene_from_handle(L, L.lt_host_scene_from_obj(str(path).encode()), camera)
+
+
+def build_from_triangles(positions, normals, material_indices, materials, camera=None):
+    """positions, normals: float32 [N,3,3]; material_indices: int32 [N]; materials: MATERIAL_DTYPE [K]."""
+    import ctypes
+    L = _host_lib()
+    pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 9)
+    nrm = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 9)
+    mi = np.ascontiguousarray(material_indices, dtype=np.int32)
+    mats = np.ascontiguousarray(materials).view(np.uint8)
+    if pos.shape != nrm.shape or mi.shape[0] != pos.shape[0]:
+        raise ValueError("triangle arrays disagree in length")
+    vp = ctypes.c_void_p
+    h = L.lt_host_scene_from_triangles(pos.ctypes.data_as(vp), nrm.ctypes.data_as(vp), mi.ctypes.data_as(vp), pos.shape[0],
+                                       mats.ctypes.data_as(vp), mats.size // 32)
+    return _scene_from_handle(L, h, camera)

@@ -1,0 +1,113 @@
+"""Synthetic scenes for the BASELINE.json configurations (there are no bunny / Sponza assets in the reference and
+no network): closed-form or fixed-seed geometry, smooth vertex normals, one emissive quad (2 triangles), every
+triangle with a material -- the preconditions of the reference's loader.  All scenes are framed for
+the reference camera (0, 2.5, -50), whose view at z = 0 spans x in [-4.5, 4.5], y in [-2, 7]."""
+import numpy as np
+
+from .scene import MATERIAL_DTYPE, build_from_triangles, camera_bytes
+
+
+def _materials(colors):
+    m = np.zeros(len(colors) + 1, dtype=MATERIAL_DTYPE)
+    m["ior"] = 1.45
+    m["dissolve"] = 1.0
+    for i, c in enumerate(colors):
+        m[i]["diffuse"] = c
+    m[-1]["diffuse"] = (0.8, 0.8, 0.8)
+    m[-1]["emission"] = (1.0, 1.0, 1.0)     # last material = the light
+    return m
+
+
+def _light_quad(x0, x1, y, z0, z1):
+    """Two emissive triangles facing -y, above and in front of the geometry, outside the camera's view."""
+    p = np.float32([[[x0, y, z0], [x1, y, z0], [x1, y, z1]], [[x0, y, z0], [x1, y, z1], [x0, y, z1]]])
+    n = np.tile(np.float32([0, -1, 0]), (2, 3, 1))
+    return p, n
+
+
+def _grid_triangles(P, N):
+    """P, N: [ny+1, nx+1, 3] vertex positions / normals -> two triangles per cell."""
+    a, b, c, d = P[:-1, :-1], P[:-1, 1:], P[1:, 1:], P[1:, :-1]
+    na, nb, nc, nd = N[:-1, :-1], N[:-1, 1:], N[1:, 1:], N[1:, :-1]
+    pos = np.stack([np.stack([a, b, c], axis=2), np.stack([a, c, d], axis=2)], axis=2).reshape(-1, 3, 3)
+    nrm = np.stack([np.stack([na, nb, nc], axis=2), np.stack([na, nc, nd], axis=2)], axis=2).reshape(-1, 3, 3)
+    return pos.astype(np.float32), nrm.astype(np.float32)
+
+
+def heightfield_wall(cells=708, camera=None):
+    """Config 4: a cells x cells height-field wall over x in [-5,5], y in [-2.5,7.5] that fills the frame
+    (2*cells^2 triangles: 708 -> 1 002 528) plus a 2-triangle light.  Closed-form sines, no RNG."""
+    x = np.linspace(-5.0, 5.0, cells + 1)
+    y = np.linspace(-2.5, 7.5, cells + 1)
+    X, Y = np.meshgrid(x, y)
+    Z = 0.35 * np.sin(1.7 * X) * np.sin(1.3 * Y) + 0.08 * np.sin(9.0 * X + 5.0 * Y) + 0.03 * np.sin(23.0 * X - 17.0 * Y)
+    dZdx = 0.35 * 1.7 * np.cos(1.7 * X) * np.sin(1.3 * Y) + 0.08 * 9.0 * np.cos(9.0 * X + 5.0 * Y) + 0.03 * 23.0 * np.cos(23.0 * X - 17.0 * Y)
+    dZdy = 0.35 * 1.3 * np.sin(1.7 * X) * np.cos(1.3 * Y) + 0.08 * 5.0 * np.cos(9.0 * X + 5.0 * Y) - 0.03 * 17.0 * np.cos(23.0 * X - 17.0 * Y)
+    P = np.stack([X, Y, Z], axis=-1)
+    N = np.stack([dZdx, dZdy, -np.ones_like(Z)], axis=-1)     # facing the camera (-z)
+    N /= np.linalg.norm(N, axis=-1, keepdims=True)
+    pos, nrm = _grid_triangles(P, N)
+    # three colour bands so the image is not monochrome
+    band = (np.arange(pos.shape[0]) // (2 * cells)) * 3 // cells
+    lp, ln = _light_quad(-1.5, 1.5, 9.5, -9.0, -6.0)
+    mats = _materials([(0.8, 0.8, 0.8), (0.9, 0.3, 0.25), (0.3, 0.75, 0.35)])
+    pos = np.concatenate([pos, lp])
+    nrm = np.concatenate([nrm, ln])
+    mi = np.concatenate([band.astype(np.int32), np.full(2, len(mats) - 1, dtype=np.int32)])
+    return build_from_triangles(pos, nrm, mi, mats, camera or camera_bytes(0.0, 2.5, -50.0))
+
+
+def triangle_soup(count=1000000, seed=1, camera=None):
+    """Config 4 variant with incoherent traversal: `count` small random triangles in a slab in front of a back
+    wall, fixed seed."""
+    rng = np.random.default_rng(seed)
+    c = np.stack([rng.uniform(-5, 5, count), rng.uniform(-2.5, 7.5, count), rng.uniform(-3.0, 0.0, count)], axis=-1)
+    e = rng.normal(0.0, 0.03, (count, 3, 3))
+    pos = (c[:, None, :] + e).astype(np.float32)
+    n = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0])
+    n /= np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-20)
+    n *= np.where(n[:, 2:3] > 0, -1.0, 1.0)                  # face the camera
+    nrm = np.repeat(n[:, None, :], 3, axis=1).astype(np.float32)
+    wall_p = np.float32([[[-6, -3.5, 0.2], [6, -3.5, 0.2], [6, 8.5, 0.2]], [[-6, -3.5, 0.2], [6, 8.5, 0.2], [-6, 8.5, 0.2]]])
+    wall_n = np.tile(np.float32([0, 0, -1]), (2, 3, 1))
+    lp, ln = _light_quad(-1.5, 1.5, 9.5, -9.0, -6.0)
+    mats = _materials([(0.8, 0.8, 0.8), (0.9, 0.3, 0.25), (0.3, 0.75, 0.35), (0.3, 0.4, 0.9)])
+    mi = np.concatenate([rng.integers(0, 4, count).astype(np.int32), np.zeros(2, np.int32), np.full(2, len(mats) - 1, np.int32)])
+    return build_from_triangles(np.concatenate([pos, wall_p, lp]), np.concatenate([nrm, wall_n, ln]), mi, mats,
+                                camera or camera_bytes(0.0, 2.5, -50.0))
+
+
+def blob_in_box(subdiv=5, camera=None):
+    """Config 3: a displaced, subdivided sphere (20 * 4^subdiv... here a lat-long sphere of ~70 k triangles at the
+    default) inside a 5-wall box with a 2-triangle light."""
+    nu = nv = int(round(np.sqrt(70000 / 2)))                  # ~187 x 187 cells -> ~70 k triangles
+    if subdiv != 5:
+        nu = nv = max(8, int(round(np.sqrt(70000 / 2) * 2.0 ** (subdiv - 5))))
+    u = np.linspace(0.0, 2.0 * np.pi, nu + 1)
+    v = np.linspace(1e-3, np.pi - 1e-3, nv + 1)
+    U, V = np.meshgrid(u, v)
+    R = 1.6 + 0.18 * np.sin(5 * U) * np.sin(4 * V) + 0.07 * np.sin(13 * U + 3.0) * np.sin(11 * V)
+    P = np.stack([R * np.sin(V) * np.cos(U), 2.5 + R * np.cos(V), -2.5 + R * np.sin(V) * np.sin(U)], axis=-1)
+    dU = np.gradient(P, axis=1)
+    dV = np.gradient(P, axis=0)
+    N = np.cross(dV, dU)
+    N /= np.maximum(np.linalg.norm(N, axis=-1, keepdims=True), 1e-20)
+    pos, nrm = _grid_triangles(P, N)
+    quads = []
+
+    def quad(a, b, c, d, n):
+        quads.append((np.float32([[a, b, c], [a, c, d]]), np.tile(np.float32(n), (2, 3, 1))))
+
+    quad([-5, -2, -6], [5, -2, -6], [5, -2, 1], [-5, -2, 1], [0, 1, 0])        # floor
+    quad([-5, 7, -6], [5, 7, -6], [5, 7, 1], [-5, 7, 1], [0, -1, 0])           # ceiling
+    quad([-5, -2, 1], [5, -2, 1], [5, 7, 1], [-5, 7, 1], [0, 0, -1])           # back
+    quad([-5, -2, -6], [-5, -2, 1], [-5, 7, 1], [-5, 7, -6], [1, 0, 0])        # left
+    quad([5, -2, -6], [5, -2, 1], [5, 7, 1], [5, 7, -6], [-1, 0, 0])           # right
+    wp = np.concatenate([q[0] for q in quads])
+    wn = np.concatenate([q[1] for q in quads])
+    lp, ln = _light_quad(-1.0, 1.0, 6.9, -4.0, -2.0)
+    mats = _materials([(0.8, 0.8, 0.8), (0.9, 0.3, 0.25), (0.3, 0.75, 0.35), (0.85, 0.75, 0.3)])
+    mi = np.concatenate([np.full(pos.shape[0], 3, np.int32), np.int32([0, 0, 0, 0, 0, 0, 1, 1, 2, 2]),
+                         np.full(2, len(mats) - 1, np.int32)])
+    return build_from_triangles(np.concatenate([pos, wp, lp]), np.concatenate([nrm, wn, ln]), mi, mats,
+                                camera or camera_bytes(0.0, 2.5, -50.0))
