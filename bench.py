@@ -44,7 +44,6 @@ def parse():
     ap.add_argument("--program", default="accumulator")
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of one 4K frame for the CPU baseline sample (0 = auto, ~10-30 s)")
     return ap.parse_args()
 
 
@@ -190,20 +189,20 @@ def cpu_baseline(args, scene, program):
     from oracle import pyoracle as po
     cores = len(os.sched_getaffinity(0))
     W, H = args.width, args.height
-    cam = sc.camera_with_frame(scene.camera, 1)
-    band = args.cpu_rows
-    if band <= 0:
-        # calibrate on 8 rows, then size the sample for ~15 s
-        t0 = time.perf_counter()
-        _, st = po.render(scene, cam, W, H, program, threads=cores, rows=(H // 2, H // 2 + 8), want_stats=True)
-        dt = max(time.perf_counter() - t0, 1e-3)
-        band = int(max(8, min(H, 8 * 15.0 / dt)))
-    y0 = max(0, (H - band) // 2)
+    # calibrate on frame 1, then render whole frames (frameCount 1, 2, ...) for ~15 s of CPU work
     t0 = time.perf_counter()
-    _, st = po.render(scene, cam, W, H, program, threads=cores, rows=(y0, y0 + band), want_stats=True)
+    _, st = po.render(scene, sc.camera_with_frame(scene.camera, 1), W, H, program, threads=cores, want_stats=True)
+    dt1 = max(time.perf_counter() - t0, 1e-3)
+    frames = int(max(1, min(args.spp, round(15.0 / dt1))))
+    rays = 0
+    t0 = time.perf_counter()
+    for f in range(1, frames + 1):
+        _, st = po.render(scene, sc.camera_with_frame(scene.camera, f), W, H, program, threads=cores, want_stats=True)
+        rays += st["rays"]
     dt = time.perf_counter() - t0
-    return {"value": round(st["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "rows %d..%d of frame 1 (%dx%d, %d rays) in %.1f s" % (y0, y0 + band, W, H, st["rays"], dt)}
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d whole frames (frameCount 1..%d) of the workload, %dx%d, %d rays in %.1f s on %d threads" % (
+                frames, frames, W, H, rays, dt, cores)}
 
 
 if __name__ == "__main__":
