@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,7 +15,8 @@
 using namespace lt;
 
 // ---------------------------------------------------------------------------------- kernels
-// One lane per pixel; a wavefront covers an 8x8 pixel square, a workgroup 16x16.  Workgroup ids are
+// One lane per pixel; a workgroup is ONE wavefront covering an 8x8 pixel square (no intra-workgroup tail: the
+// LDS stack and the wave slot are released as soon as that wave's slowest ray ends).  Workgroup ids are
 // remapped so that the blocks one XCD receives (ids congruent mod 8) cover one contiguous part of the
 // image: each XCD's private L2 then holds the BVH subtrees of its own image region.
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
@@ -25,7 +27,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 template <int PROGRAM, bool DEEP, bool STATS>
 __global__ __launch_bounds__(kBlock) void lt_render_kernel(SceneDev sc, FrameParams fp, float* __restrict__ out,
                                                           unsigned long long* __restrict__ stats) {
-  __shared__ int lds_stack[kLdsStack * kBlock];
+  extern __shared__ int lds_stack[];   // [min(height + 1, kLdsStack)][kBlock], sized by the launch
   Stack<DEEP> st;
   st.lds = lds_stack + threadIdx.x;
   Counters c{0, 0, 0, 0};
@@ -35,9 +37,9 @@ __global__ __launch_bounds__(kBlock) void lt_render_kernel(SceneDev sc, FramePar
   const uint32_t sbx = sb % fp.blocksPerTileX, sby = sb / fp.blocksPerTileX;
   const uint32_t tile = fp.tileFirst + k * fp.tileStride;
   const uint32_t tx = tile % fp.tilesX, ty = tile / fp.tilesX;
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const uint32_t lx = sbx * 16u + (wave & 1u) * 8u + (lane & 7u);
-  const uint32_t ly = sby * 16u + (wave >> 1) * 8u + (lane >> 3);
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lx = sbx * 8u + (lane & 7u);
+  const uint32_t ly = sby * 8u + (lane >> 3);
   const uint32_t x = tx * fp.tileW + lx, y = ty * fp.tileH + ly;
   const bool valid = k < fp.tilesInCall && lx < fp.tileW && ly < fp.tileH && x < fp.width && y < fp.height;
   if (valid) {
@@ -297,8 +299,8 @@ static int plan_tiles(const lt_hip_render_desc* d, TilePlan& p, std::string& msg
   p.tilesY = (d->height + p.tileH - 1) / p.tileH;
   const uint32_t total = p.tilesX * p.tilesY;
   p.tilesInCall = p.tileFirst < total ? (total - p.tileFirst + p.tileStride - 1) / p.tileStride : 0;
-  p.bptx = (p.tileW + 15) / 16;
-  p.bpty = (p.tileH + 15) / 16;
+  p.bptx = (p.tileW + 7) / 8;
+  p.bpty = (p.tileH + 7) / 8;
   p.floats = (uint64_t)p.tilesInCall * p.tileW * p.tileH * d->depth;
   return LT_OK;
 }
@@ -314,14 +316,14 @@ extern "C" int lt_hip_output_floats(const lt_hip_render_desc* desc, uint64_t* ou
 }
 
 template <int PROGRAM>
-static void launch_program(bool deep, bool stats, dim3 grid, hipStream_t s, const SceneDev& sc, const FrameParams& fp, float* out,
-                           unsigned long long* st) {
+static void launch_program(bool deep, bool stats, dim3 grid, uint32_t lds, hipStream_t s, const SceneDev& sc, const FrameParams& fp,
+                           float* out, unsigned long long* st) {
   if (deep) {
-    if (stats) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, true, true>), grid, dim3(kBlock), 0, s, sc, fp, out, st);
-    else hipLaunchKernelGGL((lt_render_kernel<PROGRAM, true, false>), grid, dim3(kBlock), 0, s, sc, fp, out, st);
+    if (stats) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, true, true>), grid, dim3(kBlock), lds, s, sc, fp, out, st);
+    else hipLaunchKernelGGL((lt_render_kernel<PROGRAM, true, false>), grid, dim3(kBlock), lds, s, sc, fp, out, st);
   } else {
-    if (stats) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, false, true>), grid, dim3(kBlock), 0, s, sc, fp, out, st);
-    else hipLaunchKernelGGL((lt_render_kernel<PROGRAM, false, false>), grid, dim3(kBlock), 0, s, sc, fp, out, st);
+    if (stats) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, false, true>), grid, dim3(kBlock), lds, s, sc, fp, out, st);
+    else hipLaunchKernelGGL((lt_render_kernel<PROGRAM, false, false>), grid, dim3(kBlock), lds, s, sc, fp, out, st);
   }
 }
 
@@ -381,12 +383,15 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       fp.frameCount = d->frame_count ? d->frame_first + f : camFrame;
       fp.accumulateN = (d->frame_count && d->accumulate) ? (int32_t)(d->accumulate_base + f) : -1;
       const dim3 grid((uint32_t)nblocks);
+      // LDS stack rows: the traversal stack never holds more entries than the BVH has interior levels
+      uint32_t lds = (uint32_t)std::min(ctx->bvh_height + 1, kLdsStack) * kBlock * sizeof(int);
+      if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
       switch (d->program) {
-        case LT_PROGRAM_BASIC: launch_program<kBasic>(deep, stats, grid, s, sc, fp, out_device, ctx->d_stats); break;
-        case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(deep, stats, grid, s, sc, fp, out_device, ctx->d_stats); break;
-        case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(deep, stats, grid, s, sc, fp, out_device, ctx->d_stats); break;
-        case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(deep, stats, grid, s, sc, fp, out_device, ctx->d_stats); break;
-        default: launch_program<kGI25>(deep, stats, grid, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_BASIC: launch_program<kBasic>(deep, stats, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(deep, stats, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(deep, stats, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(deep, stats, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        default: launch_program<kGI25>(deep, stats, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
       }
       LT_HIP_CHECK(ctx, hipGetLastError());
       launches++;

@@ -18,8 +18,8 @@
 
 namespace lt {
 
-constexpr int kBlock = 256;        // threads per workgroup (4 wavefronts of 64)
-constexpr int kLdsStack = 32;      // traversal-stack entries per lane held in LDS
+constexpr int kBlock = 64;         // one wavefront per workgroup: a finished wave frees its LDS and wave slot at once
+constexpr int kLdsStack = 32;      // most traversal-stack entries per lane held in LDS (the launch sizes LDS to the scene's BVH height)
 constexpr int kMaxStack = 64;      // the reference's nodesToVisit[64] (acc.cl:137)
 constexpr float kFltMax = 3.402823466e+38f;
 
@@ -165,31 +165,54 @@ struct Stack {
 // first by dirIsNeg[axis]), same box test (acc.cl:113-130, no clipping against the closest hit), leaf =
 // primitives[primitivesOffset] only (the reference's leaf loop never adds i; re-testing the same triangle
 // primitiveCount times leaves the payload unchanged after the first test, so it is tested once here).
-template <int PROGRAM, bool DEEP, bool STATS>
-__device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgnore, int ignore, Hit& pl,
-                                Stack<DEEP>& st, Counters& c) {
-  if (STATS) c.rays++;
-  const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;   // (float)(1.0/(double)x) == 1.0f/x
+// The reference's slab test (acc.cl:113-130), compare for compare.  Its NaN behaviour matters: an axis-parallel ray
+// has invDir = +-inf, and (bound - origin) * inf is NaN whenever the origin lies on the bound's plane; the
+// reference's `if (tyMin > tMin) tMin = tyMin` forms then keep or drop the NaN in a definite way.
+__device__ __forceinline__ bool box_test_reference(const float4 a, const float4 b, const Ray& ray, float ix, float iy, float iz,
+                                                   bool nx, bool ny, bool nz) {
+  float tMin = ((nx ? a.w : a.x) - ray.o.x) * ix;
+  float tMax = ((nx ? a.x : a.w) - ray.o.x) * ix;
+  const float tyMin = ((ny ? b.x : a.y) - ray.o.y) * iy;
+  const float tyMax = ((ny ? a.y : b.x) - ray.o.y) * iy;
+  bool hit = !(tMin > tyMax || tyMin > tMax);
+  if (tyMin > tMin) tMin = tyMin;
+  if (tyMax < tMax) tMax = tyMax;
+  const float tzMin = ((nz ? b.y : a.z) - ray.o.z) * iz;
+  const float tzMax = ((nz ? a.z : b.y) - ray.o.z) * iz;
+  hit = hit && !(tMin > tzMax || tzMin > tMax);
+  if (tzMin > tMin) tMin = tzMin;
+  if (tzMax < tMax) tMax = tzMax;
+  return hit && (tMax > 0.0f);
+}
+
+// The same predicate for rays whose origin and inverse direction are all finite: then no product below can be NaN
+// (finite - finite is finite, finite * finite is finite or +-inf), per axis the entry distance the reference picks by
+// dirIsNeg is min(t0, t1) and the exit distance max(t0, t1) (rounding is monotonic), and its chain of compares and
+// updates is exactly "largest entry <= smallest exit, and smallest exit > 0".  Same result, a third fewer instructions
+// (no sign selects: v_min/v_max3 instead).
+__device__ __forceinline__ bool box_test_finite(const float4 a, const float4 b, const Ray& ray, float ix, float iy, float iz) {
+  const float tx0 = (a.x - ray.o.x) * ix, tx1 = (a.w - ray.o.x) * ix;
+  const float ty0 = (a.y - ray.o.y) * iy, ty1 = (b.x - ray.o.y) * iy;
+  const float tz0 = (a.z - ray.o.z) * iz, tz1 = (b.y - ray.o.z) * iz;
+  const float tEnter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)), __builtin_fminf(tz0, tz1));
+  const float tExit = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fmaxf(tz0, tz1));
+  return tEnter <= tExit && tExit > 0.0f;
+}
+
+// acc.cl:132-171 (intersect) and :173-217 (intersectIgnorePrimitiveIndex): same node order (near child
+// first by dirIsNeg[axis]), same box test, leaf = primitives[primitivesOffset] only (the reference's leaf loop never
+// adds i; re-testing the same triangle primitiveCount times leaves the payload unchanged after the first test, so it
+// is tested once here).  FINITE selects the box-test form; the caller picks it per wave.
+template <int PROGRAM, bool DEEP, bool STATS, bool FINITE>
+__device__ inline void traverse_impl(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool useIgnore, int ignore,
+                                     Hit& pl, Stack<DEEP>& st, Counters& c) {
   const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
   int sp = 0, cur = 0;
   for (;;) {
     const float4* n = sc.nodes + 2 * (size_t)cur;
     const float4 a = n[0], b = n[1];   // a = min.x min.y min.z max.x ; b = max.y max.z offset count|axis<<16
     if (STATS) c.nodes++;
-    float tMin = ((nx ? a.w : a.x) - ray.o.x) * ix;
-    float tMax = ((nx ? a.x : a.w) - ray.o.x) * ix;
-    const float tyMin = ((ny ? b.x : a.y) - ray.o.y) * iy;
-    const float tyMax = ((ny ? a.y : b.x) - ray.o.y) * iy;
-    bool hit = !(tMin > tyMax || tyMin > tMax);
-    if (tyMin > tMin) tMin = tyMin;
-    if (tyMax < tMax) tMax = tyMax;
-    const float tzMin = ((nz ? b.y : a.z) - ray.o.z) * iz;
-    const float tzMax = ((nz ? a.z : b.y) - ray.o.z) * iz;
-    hit = hit && !(tMin > tzMax || tzMin > tMax);
-    if (tzMin > tMin) tMin = tzMin;
-    if (tzMax < tMax) tMax = tzMax;
-    hit = hit && (tMax > 0.0f);
-
+    const bool hit = FINITE ? box_test_finite(a, b, ray, ix, iy, iz) : box_test_reference(a, b, ray, ix, iy, iz, nx, ny, nz);
     const uint32_t meta = __float_as_uint(b.w);
     const int off = __float_as_int(b.z);
     const uint32_t count = meta & 0xffffu;
@@ -211,6 +234,22 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
     }
     if (sp == 0) break;
     cur = st.pop(--sp);
+  }
+}
+
+template <int PROGRAM, bool DEEP, bool STATS>
+__device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgnore, int ignore, Hit& pl,
+                                Stack<DEEP>& st, Counters& c) {
+  if (STATS) c.rays++;
+  const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;   // (float)(1.0/(double)x) == 1.0f/x
+  // |x| < inf is false for NaN and for +-inf
+  const bool finite = __builtin_fabsf(ix) < __builtin_inff() && __builtin_fabsf(iy) < __builtin_inff() &&
+                      __builtin_fabsf(iz) < __builtin_inff() && __builtin_fabsf(ray.o.x) < __builtin_inff() &&
+                      __builtin_fabsf(ray.o.y) < __builtin_inff() && __builtin_fabsf(ray.o.z) < __builtin_inff();
+  if (__all(finite)) {
+    traverse_impl<PROGRAM, DEEP, STATS, true>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
+  } else {   // e.g. the image-centre column/row, where a direction component is exactly 0
+    traverse_impl<PROGRAM, DEEP, STATS, false>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
   }
 }
 
