@@ -78,8 +78,12 @@ enum { LT_KERNEL_MODE_LINEAR = 0, LT_KERNEL_MODE_TILE = 1 };
 
 enum {
   LT_RENDER_FLAG_STATS = 1u,    /* count rays / node visits / triangle tests with device atomics (slower) */
-  LT_RENDER_FLAG_PIXEL_COUNTERS = 2u /* diagnostic (implies STATS, needs depth >= 4): instead of the colour, write each
+  LT_RENDER_FLAG_PIXEL_COUNTERS = 2u,/* diagnostic (implies STATS, needs depth >= 4): instead of the colour, write each
                                         pixel's own {rays, shadow rays, node visits, triangle tests} as 4 floats */
+  LT_RENDER_FLAG_DEVICE_LIBM = 4u    /* use the GPU device library's rsqrt / sqrt / sinf / cosf / clamp exactly as ROCm's OpenCL
+                                        gives them to the reference kernels (v_rsq_f32, v_sqrt_f32, ocml trig, v_med3_f32)
+                                        instead of the portable correctly-rounded forms the CPU oracle reproduces: makes the
+                                        output bit-identical to the reference's OpenCL kernels on this GPU */
 };
 
 typedef struct lt_hip_render_desc {

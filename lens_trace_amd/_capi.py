@@ -15,6 +15,7 @@ PROGRAM_BASIC, PROGRAM_BASIC_LIGHTING, PROGRAM_ACCUMULATOR, PROGRAM_GLOBAL_ILLUM
 KERNEL_MODE_LINEAR, KERNEL_MODE_TILE = 0, 1
 RENDER_FLAG_STATS = 1
 RENDER_FLAG_PIXEL_COUNTERS = 2
+RENDER_FLAG_DEVICE_LIBM = 4
 
 # every symbol include/lenstrace_hip.h declares
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",

@@ -65,11 +65,37 @@ __device__ __forceinline__ V4 cross4(V4 a, V4 b) {
   return mk4(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
              __builtin_fmaf(a.x, b.y, -(a.y * b.x)), 0.0f);
 }
-// portable stand-ins for the device library's approximate rsqrt / float trig
-__device__ __forceinline__ float rsqrt_portable(float x) { return (float)(1.0 / sqrt((double)x)); }
-__device__ __forceinline__ float cosf_portable(float x) { return (float)cos((double)x); }
-__device__ __forceinline__ float sinf_portable(float x) { return (float)sin((double)x); }
+// The four leaf functions where ROCm's OpenCL device library uses a hardware approximation or its own float trig.
+//   Math<false> "portable": correctly rounded forms every IEEE machine reproduces -- the CPU oracle's definition.
+//   Math<true>  "device libm": what the reference's OpenCL kernels get on this GPU (read from their gfx950 ISA):
+//       rsqrt  = v_rsq_f32 with the library's denormal pre-scale, sqrt (inside distance) = v_sqrt_f32 with the
+//       backend's denormal scaling, sin/cos(float) = ocml's, clamp = v_med3_f32.  With it the HIP path is
+//       bit-identical to the reference's own kernels compiled for gfx950 (tests/test_gpu_reference_kernels.py).
+template <bool DEVLIBM>
+struct Math {
+  static __device__ __forceinline__ float rsqrt(float x) {
+    if (DEVLIBM) {
+      const bool small = x < 1.17549435e-38f;
+      const float r = __builtin_amdgcn_rsqf(small ? x * 0x1p+24f : x);
+      return small ? r * 4096.0f : r;
+    }
+    return (float)(1.0 / sqrt((double)x));
+  }
+  static __device__ __forceinline__ float sqrt_in_distance(float x) {
+    if (DEVLIBM) {
+      const bool small = x < 1.17549435e-38f;
+      return __builtin_ldexpf(__builtin_amdgcn_sqrtf(__builtin_ldexpf(x, small ? 32 : 0)), small ? -16 : 0);
+    }
+    return __builtin_sqrtf(x);
+  }
+  static __device__ __forceinline__ float cos(float x) { return DEVLIBM ? ::cosf(x) : (float)::cos((double)x); }
+  static __device__ __forceinline__ float sin(float x) { return DEVLIBM ? ::sinf(x) : (float)::sin((double)x); }
+  static __device__ __forceinline__ float clamp01(float x) {
+    return DEVLIBM ? __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f) : __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f);
+  }
+};
 
+template <bool DEVLIBM>
 __device__ inline V4 normalize4(V4 p) {
   if (p.x == 0.0f && p.y == 0.0f && p.z == 0.0f && p.w == 0.0f) return p;
   float l2 = dot4(p, p);
@@ -85,23 +111,22 @@ __device__ inline V4 normalize4(V4 p) {
       l2 = dot4(p, p);
     }
   }
-  return scale4(rsqrt_portable(l2), p);
+  return scale4(Math<DEVLIBM>::rsqrt(l2), p);
 }
 
+template <bool DEVLIBM>
 __device__ inline float distance4(V4 a, V4 b) {
   V4 d = sub4(a, b);
   float l2 = dot4(d, d);
   if (l2 < 1.17549435e-38f) {
     d = scale4(0x1p+86f, d);
-    return __builtin_sqrtf(dot4(d, d)) * 0x1p-86f;
+    return Math<DEVLIBM>::sqrt_in_distance(dot4(d, d)) * 0x1p-86f;
   } else if (l2 == __builtin_inff()) {
     d = scale4(0x1p-66f, d);
-    return __builtin_sqrtf(dot4(d, d)) * 0x1p+66f;
+    return Math<DEVLIBM>::sqrt_in_distance(dot4(d, d)) * 0x1p+66f;
   }
-  return __builtin_sqrtf(l2);
+  return Math<DEVLIBM>::sqrt_in_distance(l2);
 }
-
-__device__ __forceinline__ float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
 
 // acc.cl:63-66: float dot, then double add / fmod / sin / mul, then float fract
 __device__ inline float random_(float uvx, float uvy, float seed) {
@@ -281,7 +306,7 @@ __device__ __forceinline__ const float* light_prim(const SceneDev& sc, float rnd
 
 // Light sample + shadow ray: acc.cl:239-279, basic_lighting.cl:234-274, gi.cl:267-297 and :323-349.
 // normal_w is 0 in accumulator/basic_lighting, 1 in GI (extractDataFromBarycentrics returns w = 1, gi.cl:238).
-template <int PROGRAM, bool DEEP, bool STATS>
+template <int PROGRAM, bool DEEP, bool STATS, bool DEVLIBM>
 __device__ inline bool direct_light(const SceneDev& sc, const float* pr, int primIndex, float u, float v, float fx,
                                     float fy, float seedIndex, float seedU, float seedV, float normal_w, V4& position,
                                     V4& normal, float& ndotl, Stack<DEEP>& st, Counters& c) {
@@ -302,8 +327,8 @@ __device__ inline bool direct_light(const SceneDev& sc, const float* pr, int pri
   const V3 l3 = bary3(lp + 0, lp + 3, lp + 6, lb);
   const V4 lightPosition = mk4(l3.x, l3.y, l3.z, 1.0f);
 
-  const V4 toLight = normalize4(sub4(lightPosition, position));
-  Hit spl{0, 0, (float)((double)distance4(position, lightPosition) - 0.01), 0.0f, 0.0f};
+  const V4 toLight = normalize4<DEVLIBM>(sub4(lightPosition, position));
+  Hit spl{0, 0, (float)((double)distance4<DEVLIBM>(position, lightPosition) - 0.01), 0.0f, 0.0f};
   const Ray shadowRay{position, toLight};
   if (STATS) c.shadow++;
   traverse<PROGRAM, DEEP, STATS>(sc, shadowRay, true, primIndex, spl, st, c);
@@ -373,7 +398,7 @@ __device__ inline V3 shade_basic(const SceneDev& sc, Ray ray, Stack<DEEP>& st, C
 }
 
 // acc.cl:219-282 / basic_lighting.cl:220-277
-template <int PROGRAM, bool DEEP, bool STATS>
+template <int PROGRAM, bool DEEP, bool STATS, bool DEVLIBM>
 __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, float fx, float fy, uint32_t s,
                                     Stack<DEEP>& st, Counters& c) {
   V3 out{0.0f, 0.0f, 0.0f};
@@ -387,7 +412,7 @@ __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, fl
     const Material* m = sc.mats + prim_material(pr);
     V4 position, normal;
     float ndotl;
-    if (direct_light<PROGRAM, DEEP, STATS>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u),
+    if (direct_light<PROGRAM, DEEP, STATS, DEVLIBM>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u),
                                            0.0f, position, normal, ndotl, st, c)) {
       out = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
     }
@@ -396,21 +421,23 @@ __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, fl
 }
 
 // gi.cl:68-74
+template <bool DEVLIBM>
 __device__ inline V4 uniform_sample_hemisphere(float uvx, float uvy) {
   const float z = uvx;
   const float r = __builtin_sqrtf(__builtin_fmaxf(0.0f, 1.0f - z * z));
   const float phi = (float)(2.0 * M_PI * (double)uvy);
-  return mk4(r * cosf_portable(phi), z, r * sinf_portable(phi), 0.0f);
+  return mk4(r * Math<DEVLIBM>::cos(phi), z, r * Math<DEVLIBM>::sin(phi), 0.0f);
 }
 // gi.cl:76-81
+template <bool DEVLIBM>
 __device__ inline V4 align_hemisphere(V4 h, V4 up) {
-  const V4 right = normalize4(cross4(up, mk4(0.0072f, 1.0f, 0.0034f, 0.0f)));
+  const V4 right = normalize4<DEVLIBM>(cross4(up, mk4(0.0072f, 1.0f, 0.0034f, 0.0f)));
   const V4 forward = cross4(right, up);
   return add4(add4(scale4(h.x, right), scale4(h.y, up)), scale4(h.z, forward));
 }
 
 // gi.cl:241-375
-template <bool DEEP, bool STATS>
+template <bool DEEP, bool STATS, bool DEVLIBM>
 __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx, float fy, uint32_t s, int maxDepth,
                               Stack<DEEP>& st, Counters& c) {
   V3 direct{0.0f, 0.0f, 0.0f}, indirect{0.0f, 0.0f, 0.0f};
@@ -423,12 +450,12 @@ __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx
     const Material* m = sc.mats + prim_material(pr);
     V4 position, normal;
     float ndotl;
-    if (direct_light<kGI, DEEP, STATS>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u), 1.0f,
+    if (direct_light<kGI, DEEP, STATS, DEVLIBM>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u), 1.0f,
                                        position, normal, ndotl, st, c)) {
       direct = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
     }
-    V4 hemi = uniform_sample_hemisphere(random_(fx, fy, (float)(s + 3u)), random_(fx, fy, (float)(s + 4u)));
-    Ray ext{position, align_hemisphere(hemi, normal)};
+    V4 hemi = uniform_sample_hemisphere<DEVLIBM>(random_(fx, fy, (float)(s + 3u)), random_(fx, fy, (float)(s + 4u)));
+    Ray ext{position, align_hemisphere<DEVLIBM>(hemi, normal)};
     V4 previousNormal = normal;
     int previousPrimitive = pl.prim;
     bool rayActive = true;
@@ -448,14 +475,14 @@ __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx
         const Material* em = sc.mats + prim_material(epr);
         V4 epos, enorm;
         float endotl;
-        if (direct_light<kGI, DEEP, STATS>(sc, epr, epl.prim, epl.u, epl.v, fx, fy, (float)(sd + 5u), (float)(sd + 6u),
+        if (direct_light<kGI, DEEP, STATS, DEVLIBM>(sc, epr, epl.prim, epl.u, epl.v, fx, fy, (float)(sd + 5u), (float)(sd + 6u),
                                            (float)(sd + 7u), 1.0f, epos, enorm, endotl, st, c)) {
           indirect.x += (w * em->diffuse[0]) * endotl;
           indirect.y += (w * em->diffuse[1]) * endotl;
           indirect.z += (w * em->diffuse[2]) * endotl;
-          hemi = uniform_sample_hemisphere(random_(fx, fy, (float)(sd + 8u)), random_(fx, fy, (float)(sd + 9u)));
+          hemi = uniform_sample_hemisphere<DEVLIBM>(random_(fx, fy, (float)(sd + 8u)), random_(fx, fy, (float)(sd + 9u)));
           ext.o = epos;
-          ext.d = align_hemisphere(hemi, enorm);
+          ext.d = align_hemisphere<DEVLIBM>(hemi, enorm);
           previousNormal = enorm;
           previousPrimitive = epl.prim;
         } else {
@@ -469,15 +496,15 @@ __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx
   return V3{direct.x + indirect.x, direct.y + indirect.y, direct.z + indirect.z};
 }
 
-// Per-frame uniforms.  cos/sin(yaw) are evaluated once on the host as (float)cos((double)yaw): the
-// reference evaluates cos(camera->yaw) per work-item (acc.cl:309-310), a uniform.
+// Per-frame uniforms.  cos/sin(yaw) are evaluated once on the host as (float)cos((double)yaw) (portable math); the
+// reference evaluates cos(camera->yaw) per work-item (acc.cl:309-310) -- the device-libm flavour does the same.
 struct FrameParams {
   float camx, camy, camz;
   // aperaturePosition (0, 0, 5) of acc.cl:306, passed as run-time values on purpose: with a literal 0 the
   // compiler folds `0.0f - film` into a negate source modifier on the consumers (1/d), which turns the +0
   // direction component of the image-centre column/row into -0 and flips dirIsNeg there.
   float apx, apy, apz;
-  float cosYaw, sinYaw;
+  float cosYaw, sinYaw, yaw;
   uint32_t frameCount;
   uint32_t width, height, depth;
   int32_t clampOutput;      // linearKernel of the lighting programs clamps, tileKernel does not (acc.cl:316-318/:356-358)
@@ -490,13 +517,15 @@ struct FrameParams {
 };
 
 // Camera ray of pixel (x,y): acc.cl:304-312.
+template <bool DEVLIBM>
 __device__ __forceinline__ Ray camera_ray(const FrameParams& fp, int x, int y, float& fx, float& fy) {
   const V4 cameraPosition = mk4(fp.camx, fp.camy, fp.camz, 1.0f);
   const V4 film = mk4(((float)x / (float)fp.width) - 0.5f, ((float)y / (float)fp.height) - 0.5f, 0.0f, 1.0f);
   const V4 aperture = mk4(fp.apx, fp.apy, fp.apz, 1.0f);
   Ray ray{add4(cameraPosition, film), sub4(aperture, film)};
-  const float newX = (fp.cosYaw * ray.d.x) + (fp.sinYaw * ray.d.z);
-  const float newZ = (-fp.sinYaw * ray.d.x) + (fp.cosYaw * ray.d.z);
+  const float cy = DEVLIBM ? ::cosf(fp.yaw) : fp.cosYaw, sy = DEVLIBM ? ::sinf(fp.yaw) : fp.sinYaw;
+  const float newX = (cy * ray.d.x) + (sy * ray.d.z);
+  const float newZ = (-sy * ray.d.x) + (cy * ray.d.z);
   ray.d.x = newX;
   ray.d.z = newZ;
   fx = film.x;
@@ -506,23 +535,23 @@ __device__ __forceinline__ Ray camera_ray(const FrameParams& fp, int x, int y, f
 
 // The body of linearKernel / tileKernel for one pixel, all five programs
 // (acc.cl:314-318, basic.cl:338-342, basic_lighting.cl:309-321, resources gi :408-420).
-template <int PROGRAM, bool DEEP, bool STATS>
+template <int PROGRAM, bool DEEP, bool STATS, bool DEVLIBM>
 __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int x, int y, Stack<DEEP>& st, Counters& c) {
   float fx, fy;
-  const Ray ray = camera_ray(fp, x, y, fx, fy);
+  const Ray ray = camera_ray<DEVLIBM>(fp, x, y, fx, fy);
   V3 color;
   if (PROGRAM == kBasic) {
     color = shade_basic<DEEP, STATS>(sc, ray, st, c);
   } else if (PROGRAM == kAccumulator) {
-    color = shade_lighting<kAccumulator, DEEP, STATS>(sc, ray, fx, fy, fp.frameCount, st, c);
+    color = shade_lighting<kAccumulator, DEEP, STATS, DEVLIBM>(sc, ray, fx, fy, fp.frameCount, st, c);
   } else if (PROGRAM == kGI) {
-    color = shade_gi<DEEP, STATS>(sc, ray, fx, fy, fp.frameCount, fp.giMaxDepth, st, c);
+    color = shade_gi<DEEP, STATS, DEVLIBM>(sc, ray, fx, fy, fp.frameCount, fp.giMaxDepth, st, c);
   } else {
     const uint32_t base = fp.frameCount * 32u;
     for (int k = 0; k < 25; k++) {
       const V3 cn = (PROGRAM == kBasicLighting)
-                        ? shade_lighting<kBasicLighting, DEEP, STATS>(sc, ray, fx, fy, base + (uint32_t)k, st, c)
-                        : shade_gi<DEEP, STATS>(sc, ray, fx, fy, base + (uint32_t)k, fp.giMaxDepth, st, c);
+                        ? shade_lighting<kBasicLighting, DEEP, STATS, DEVLIBM>(sc, ray, fx, fy, base + (uint32_t)k, st, c)
+                        : shade_gi<DEEP, STATS, DEVLIBM>(sc, ray, fx, fy, base + (uint32_t)k, fp.giMaxDepth, st, c);
       if (k == 0) {
         color = cn;
       } else {
@@ -532,7 +561,7 @@ __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int 
       }
     }
   }
-  if (PROGRAM != kBasic && fp.clampOutput) color = V3{clamp01(color.x), clamp01(color.y), clamp01(color.z)};
+  if (PROGRAM != kBasic && fp.clampOutput) color = V3{Math<DEVLIBM>::clamp01(color.x), Math<DEVLIBM>::clamp01(color.y), Math<DEVLIBM>::clamp01(color.z)};
   return color;
 }
 

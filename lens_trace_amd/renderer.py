@@ -41,10 +41,11 @@ class RenderPropertiesHIP:
     giMaxDepth: int = 0
     collectStats: bool = False
     pixelCounters: bool = False                  # diagnostic: per-pixel work counters instead of colour (depth >= 4)
+    deviceLibm: bool = False                     # bit-match ROCm's OpenCL builtins (v_rsq_f32, ocml sinf/cosf, ...)
 
 
 def make_desc(program, W, H, depth, camera28, kernel_mode=KERNEL_MODE_LINEAR, frame_first=0, frame_count=0,
-              accumulate=False, accumulate_base=0, tile=None, gi_max_depth=0, stats=False, pixel_counters=False):
+              accumulate=False, accumulate_base=0, tile=None, gi_max_depth=0, stats=False, pixel_counters=False, device_libm=False):
     d = C.RenderDesc()
     d.struct_size = ctypes.sizeof(C.RenderDesc)
     d.program, d.kernel_mode = program, kernel_mode
@@ -58,7 +59,8 @@ def make_desc(program, W, H, depth, camera28, kernel_mode=KERNEL_MODE_LINEAR, fr
     if tile is not None:
         d.tile_w, d.tile_h, d.tile_first, d.tile_stride = tile
     d.gi_max_depth = gi_max_depth
-    d.flags = (C.RENDER_FLAG_STATS if stats else 0) | (C.RENDER_FLAG_PIXEL_COUNTERS if pixel_counters else 0)
+    d.flags = ((C.RENDER_FLAG_STATS if stats else 0) | (C.RENDER_FLAG_PIXEL_COUNTERS if pixel_counters else 0) |
+               (C.RENDER_FLAG_DEVICE_LIBM if device_libm else 0))
     return d
 
 
@@ -109,7 +111,7 @@ class RendererHIP:
             self.set_scene(props.pAccelerationStructureExplicit, props.pModel)
         program = C.program_from_path(props.kernelFilePath)
         d = make_desc(program, W, H, D, props.pCamera, props.kernelMode, props.frameFirst, props.frameCount,
-                      props.accumulate, props.accumulateBase, None, props.giMaxDepth, props.collectStats, props.pixelCounters)
+                      props.accumulate, props.accumulateBase, None, props.giMaxDepth, props.collectStats, props.pixelCounters, props.deviceLibm)
         self._check(self._L.lt_hip_render(self._ctx, ctypes.byref(d), out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
 
     # -- device-resident variants (bench / multi-GPU) -----------------------------------------------------
