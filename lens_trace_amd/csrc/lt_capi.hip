@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kBlock) void lt_render_kernel(SceneDev sc, FramePar
   extern __shared__ int lds_stack[];   // [min(height + 1, kLdsStack)][kBlock], sized by the launch
   Stack<DEEP> st;
   st.lds = lds_stack + threadIdx.x;
-  Counters c{0, 0, 0, 0};
+  Counters c{};
 
   const uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
   const uint32_t k = b / fp.blocksPerTile, sb = b % fp.blocksPerTile;
@@ -61,6 +61,11 @@ __global__ __launch_bounds__(kBlock) void lt_render_kernel(SceneDev sc, FramePar
     atomicAdd(&stats[1], (unsigned long long)c.shadow);
     atomicAdd(&stats[2], (unsigned long long)c.nodes);
     atomicAdd(&stats[3], (unsigned long long)c.tris);
+#ifdef LT_DEBUG_WAVE_COUNTERS
+    atomicAdd(&stats[4], (unsigned long long)c.wInner);
+    atomicAdd(&stats[5], (unsigned long long)c.wTri);
+    atomicAdd(&stats[6], (unsigned long long)c.wOuter);
+#endif
   }
 }
 
@@ -151,7 +156,7 @@ extern "C" int lt_hip_create(int device_index, lt_hip_context** out_ctx) {
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc((void**)&ctx->d_stats, 4 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc((void**)&ctx->d_stats, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   *out_ctx = ctx;
   return LT_OK;
 }
@@ -380,7 +385,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   const uint64_t nblocks = (uint64_t)p.tilesInCall * fp.blocksPerTile;
   if (nblocks > 0x7fffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many workgroups");
 
-  if (stats) LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), s));
+  if (stats) LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), s));
   LT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, s));
   uint32_t launches = 0;
   if (nblocks > 0) {
@@ -428,8 +433,12 @@ static int finish_pending(lt_hip_context* ctx) {
   LT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->last.kernel_ms = ms;
   if (ctx->pending_stats) {
-    unsigned long long h[4];
+    unsigned long long h[8];
     LT_HIP_CHECK(ctx, hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+#ifdef LT_DEBUG_WAVE_COUNTERS
+    fprintf(stderr, "[lt debug] wave-level: node steps %llu (lane-level %llu, utilisation %.3f), triangle blocks %llu (lane-level %llu, utilisation %.3f), outer iterations %llu\n",
+            h[4], h[2], (double)h[2] / (64.0 * (double)h[4]), h[5], h[3], (double)h[3] / (64.0 * (double)h[5]), h[6]);
+#endif
     ctx->last.rays = h[0]; ctx->last.shadow_rays = h[1]; ctx->last.node_visits = h[2]; ctx->last.tri_tests = h[3];
   }
   ctx->pending = false;

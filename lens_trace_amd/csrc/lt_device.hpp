@@ -48,7 +48,17 @@ struct SceneDev {
   uint32_t n_nodes, n_prims, n_mats;
 };
 
-struct Counters { uint32_t rays, shadow, nodes, tris; };
+struct Counters {
+  uint32_t rays, shadow, nodes, tris;
+#ifdef LT_DEBUG_WAVE_COUNTERS
+  uint32_t wInner, wTri, wOuter;   // wave-level executions of the node step / triangle block / outer iteration (leader lane counts)
+#endif
+};
+#ifdef LT_DEBUG_WAVE_COUNTERS
+#define LT_WAVE_COUNT(field) do { if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) c.field++; } while (0)
+#else
+#define LT_WAVE_COUNT(field) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------- builtins
 __device__ __forceinline__ V4 mk4(float x, float y, float z, float w) { return V4{x, y, z, w}; }
@@ -228,37 +238,76 @@ __device__ __forceinline__ bool box_test_finite(const float4 a, const float4 b, 
 // first by dirIsNeg[axis]), same box test, leaf = primitives[primitivesOffset] only (the reference's leaf loop never
 // adds i; re-testing the same triangle primitiveCount times leaves the payload unchanged after the first test, so it
 // is tested once here).  FINITE selects the box-test form; the caller picks it per wave.
+#ifndef LT_TRI_BATCH
+#define LT_TRI_BATCH 16     // run the deferred triangle test when this many lanes hold a leaf (or when one must flush)
+#endif
+
+// One node per iteration.  What the round-1 ablations showed: the loop is latency-bound (VALU has ~40 % slack, +27 %
+// VALU costs 5 %; removing the triangle test gains 18 %), so the dependency chain per node is what matters:
+//  * a leaf found in iteration i is only *noted* (`pend`); its triangle loads are issued in iteration i+1 right
+//    behind the next node's loads and both latencies overlap.  Exact: the reference's traversal never reads the
+//    payload (no clipping against payload.t, acc.cl:113-130), and a lane still tests its leaves in reference order;
+//  * the top of the stack is kept in a register (`tos`), LDS holds the entries below it: a pop needs no LDS
+//    round trip before the next node's address is known (the reload of `tos` is off the critical path).
 template <int PROGRAM, bool DEEP, bool STATS, bool FINITE>
 __device__ inline void traverse_impl(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool useIgnore, int ignore,
                                      Hit& pl, Stack<DEEP>& st, Counters& c) {
   const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
-  int sp = 0, cur = 0;
-  for (;;) {
+  const int ign = useIgnore ? ignore : -1;   // leaf offsets are >= 0
+  int cur = 0, sp = 0, tos = 0;              // sp entries on the stack, the top one in `tos`
+  int pend = -1;
+  uint32_t pendCount = 0;
+  bool alive = true;
+  while (alive) {
     const float4* n = sc.nodes + 2 * (size_t)cur;
     const float4 a = n[0], b = n[1];   // a = min.x min.y min.z max.x ; b = max.y max.z offset count|axis<<16
     if (STATS) c.nodes++;
+    LT_WAVE_COUNT(wInner);
     const bool hit = FINITE ? box_test_finite(a, b, ray, ix, iy, iz) : box_test_reference(a, b, ray, ix, iy, iz, nx, ny, nz);
     const uint32_t meta = __float_as_uint(b.w);
     const int off = __float_as_int(b.z);
     const uint32_t count = meta & 0xffffu;
+    const bool newLeaf = hit && count != 0 && off != ign;
+    // flush the noted leaf when enough lanes hold one, or when a lane that holds one has found the next
+    const bool flush = LT_TRI_BATCH <= 1 ? true
+                                         : (__popcll(__ballot(pend >= 0)) >= LT_TRI_BATCH || __any(pend >= 0 && newLeaf));
+    if (flush && pend >= 0) {
+      LT_WAVE_COUNT(wTri);
+      if (STATS) c.tris += pendCount;    // the reference *calls* intersectTriangle primitiveCount times
+      if (intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl)) {
+        pl.prim = pend;
+        pl.hitType = 1;
+      }
+      pend = -1;
+    }
     if (hit && count == 0) {
       const uint32_t axis = (meta >> 16) & 0xffu;
       const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
-      st.push(sp++, neg ? cur + 1 : off);
+      if (sp > 0) st.push(sp - 1, tos);
+      tos = neg ? cur + 1 : off;
+      sp++;
       cur = neg ? off : cur + 1;
-      continue;
-    }
-    if (hit) {
-      if (!(useIgnore && off == ignore)) {
-        if (STATS) c.tris += count;    // the reference *calls* intersectTriangle primitiveCount times
-        if (intersect_triangle<PROGRAM>(sc.tris, off, ray, pl)) {
-          pl.prim = off;
-          pl.hitType = 1;
-        }
+    } else {
+      if (newLeaf) {
+        pend = off;
+        pendCount = count;
+      }
+      if (sp == 0) {
+        alive = false;
+      } else {
+        cur = tos;
+        sp--;
+        if (sp > 0) tos = st.pop(sp - 1);
       }
     }
-    if (sp == 0) break;
-    cur = st.pop(--sp);
+  }
+  if (pend >= 0) {
+    LT_WAVE_COUNT(wTri);
+    if (STATS) c.tris += pendCount;
+    if (intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl)) {
+      pl.prim = pend;
+      pl.hitType = 1;
+    }
   }
 }
 
