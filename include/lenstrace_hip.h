@@ -139,7 +139,8 @@ const char* lt_hip_last_error(const lt_hip_context* ctx);
 int lt_hip_program_from_path(const char* kernel_file_path, int* out_program);
 
 /* Uploads (host pointers) and validates the four scene buffers; keeps them resident until the next
- * set_scene / destroy.  Also builds the traversal-side triangle array (48-byte stride: A, B-A, C-A).  */
+ * set_scene / destroy.  Also builds the traversal-side triangle array (48-byte stride: A, B-A, C-A).  The BVH is
+ * traversed in the uploaded LinearBVHNode layout itself. */
 int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims,
                      uint64_t prim_bytes, const void* materials, uint64_t material_bytes, const void* lights,
                      uint64_t light_bytes);

@@ -24,11 +24,12 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
   return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
 }
 
-template <int PROGRAM, bool DEEP, bool STATS, bool DEVLIBM>
+template <int PROGRAM, class CFG>
 __global__ __launch_bounds__(kBlock) void lt_render_kernel(SceneDev sc, FrameParams fp, float* __restrict__ out,
                                                           unsigned long long* __restrict__ stats) {
   extern __shared__ int lds_stack[];   // [min(height + 1, kLdsStack)][kBlock], sized by the launch
-  Stack<DEEP> st;
+  constexpr bool STATS = CFG::kStats;
+  Stack<CFG::kDeep> st;
   st.lds = lds_stack + threadIdx.x;
   Counters c{};
 
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void lt_render_kernel(SceneDev sc, FramePar
   const uint32_t x = tx * fp.tileW + lx, y = ty * fp.tileH + ly;
   const bool valid = k < fp.tilesInCall && lx < fp.tileW && ly < fp.tileH && x < fp.width && y < fp.height;
   if (valid) {
-    const V3 color = shade_pixel<PROGRAM, DEEP, STATS, DEVLIBM>(sc, fp, (int)x, (int)y, st, c);
+    const V3 color = shade_pixel<PROGRAM, CFG>(sc, fp, (int)x, (int)y, st, c);
     float* o = out + (((size_t)k * fp.tileH + ly) * fp.tileW + lx) * fp.depth;
     if (STATS && fp.pixelCounters) {
       o[0] = (float)c.rays; o[1] = (float)c.shadow; o[2] = (float)c.nodes; o[3] = (float)c.tris;
@@ -320,16 +321,18 @@ extern "C" int lt_hip_output_floats(const lt_hip_render_desc* desc, uint64_t* ou
   return LT_OK;
 }
 
+struct LaunchConfig { bool deep, stats, devlibm; };
+
 template <int PROGRAM>
-static void launch_program(bool deep, bool stats, bool devlibm, dim3 grid, uint32_t lds, hipStream_t s, const SceneDev& sc,
-                           const FrameParams& fp, float* out, unsigned long long* st) {
-#define LT_LAUNCH(D, S, M) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, D, S, M>), grid, dim3(kBlock), lds, s, sc, fp, out, st)
-  if (devlibm) {   // verification flavour: no STATS instantiation
-    if (deep) LT_LAUNCH(true, false, true); else LT_LAUNCH(false, false, true);
-  } else if (deep) {
-    if (stats) LT_LAUNCH(true, true, false); else LT_LAUNCH(true, false, false);
+static void launch_program(const LaunchConfig& k, dim3 grid, uint32_t lds, hipStream_t s, const SceneDev& sc, const FrameParams& fp,
+                           float* out, unsigned long long* st) {
+#define LT_LAUNCH(D, S, M) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, Config<D, S, M>>), grid, dim3(kBlock), lds, s, sc, fp, out, st)
+  if (k.devlibm) {          // verification flavour: no counters
+    if (k.deep) LT_LAUNCH(true, false, true); else LT_LAUNCH(false, false, true);
+  } else if (k.deep) {
+    if (k.stats) LT_LAUNCH(true, true, false); else LT_LAUNCH(true, false, false);
   } else {
-    if (stats) LT_LAUNCH(false, true, false); else LT_LAUNCH(false, false, false);
+    if (k.stats) LT_LAUNCH(false, true, false); else LT_LAUNCH(false, false, false);
   }
 #undef LT_LAUNCH
 }
@@ -381,6 +384,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   const bool deep = ctx->bvh_height > kLdsStack;
   const bool devlibm = (d->flags & LT_RENDER_FLAG_DEVICE_LIBM) != 0;
   if (devlibm && stats) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "LT_RENDER_FLAG_DEVICE_LIBM cannot be combined with the counter flags");
+  const LaunchConfig lc{deep, stats, devlibm};
   const uint32_t frames = d->frame_count ? d->frame_count : 1;
   const uint64_t nblocks = (uint64_t)p.tilesInCall * fp.blocksPerTile;
   if (nblocks > 0x7fffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many workgroups");
@@ -397,11 +401,11 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       uint32_t lds = (uint32_t)std::min(ctx->bvh_height + 1, kLdsStack) * kBlock * sizeof(int);
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
       switch (d->program) {
-        case LT_PROGRAM_BASIC: launch_program<kBasic>(deep, stats, devlibm, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
-        case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(deep, stats, devlibm, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
-        case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(deep, stats, devlibm, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
-        case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(deep, stats, devlibm, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
-        default: launch_program<kGI25>(deep, stats, devlibm, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        default: launch_program<kGI25>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
       }
       LT_HIP_CHECK(ctx, hipGetLastError());
       launches++;

@@ -203,17 +203,17 @@ struct Stack {
 // The reference's slab test (acc.cl:113-130), compare for compare.  Its NaN behaviour matters: an axis-parallel ray
 // has invDir = +-inf, and (bound - origin) * inf is NaN whenever the origin lies on the bound's plane; the
 // reference's `if (tyMin > tMin) tMin = tyMin` forms then keep or drop the NaN in a definite way.
-__device__ __forceinline__ bool box_test_reference(const float4 a, const float4 b, const Ray& ray, float ix, float iy, float iz,
-                                                   bool nx, bool ny, bool nz) {
-  float tMin = ((nx ? a.w : a.x) - ray.o.x) * ix;
-  float tMax = ((nx ? a.x : a.w) - ray.o.x) * ix;
-  const float tyMin = ((ny ? b.x : a.y) - ray.o.y) * iy;
-  const float tyMax = ((ny ? a.y : b.x) - ray.o.y) * iy;
+__device__ __forceinline__ bool box_test_reference(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray& ray,
+                                                   float ix, float iy, float iz, bool nx, bool ny, bool nz) {
+  float tMin = ((nx ? hix : lox) - ray.o.x) * ix;
+  float tMax = ((nx ? lox : hix) - ray.o.x) * ix;
+  const float tyMin = ((ny ? hiy : loy) - ray.o.y) * iy;
+  const float tyMax = ((ny ? loy : hiy) - ray.o.y) * iy;
   bool hit = !(tMin > tyMax || tyMin > tMax);
   if (tyMin > tMin) tMin = tyMin;
   if (tyMax < tMax) tMax = tyMax;
-  const float tzMin = ((nz ? b.y : a.z) - ray.o.z) * iz;
-  const float tzMax = ((nz ? a.z : b.y) - ray.o.z) * iz;
+  const float tzMin = ((nz ? hiz : loz) - ray.o.z) * iz;
+  const float tzMax = ((nz ? loz : hiz) - ray.o.z) * iz;
   hit = hit && !(tMin > tzMax || tzMin > tMax);
   if (tzMin > tMin) tMin = tzMin;
   if (tzMax < tMax) tMax = tzMax;
@@ -225,19 +225,23 @@ __device__ __forceinline__ bool box_test_reference(const float4 a, const float4 
 // dirIsNeg is min(t0, t1) and the exit distance max(t0, t1) (rounding is monotonic), and its chain of compares and
 // updates is exactly "largest entry <= smallest exit, and smallest exit > 0".  Same result, a third fewer instructions
 // (no sign selects: v_min/v_max3 instead).
-__device__ __forceinline__ bool box_test_finite(const float4 a, const float4 b, const Ray& ray, float ix, float iy, float iz) {
-  const float tx0 = (a.x - ray.o.x) * ix, tx1 = (a.w - ray.o.x) * ix;
-  const float ty0 = (a.y - ray.o.y) * iy, ty1 = (b.x - ray.o.y) * iy;
-  const float tz0 = (a.z - ray.o.z) * iz, tz1 = (b.y - ray.o.z) * iz;
+__device__ __forceinline__ bool box_test_finite(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray& ray,
+                                                float ix, float iy, float iz) {
+  const float tx0 = (lox - ray.o.x) * ix, tx1 = (hix - ray.o.x) * ix;
+  const float ty0 = (loy - ray.o.y) * iy, ty1 = (hiy - ray.o.y) * iy;
+  const float tz0 = (loz - ray.o.z) * iz, tz1 = (hiz - ray.o.z) * iz;
   const float tEnter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)), __builtin_fminf(tz0, tz1));
   const float tExit = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fmaxf(tz0, tz1));
   return tEnter <= tExit && tExit > 0.0f;
 }
 
-// acc.cl:132-171 (intersect) and :173-217 (intersectIgnorePrimitiveIndex): same node order (near child
-// first by dirIsNeg[axis]), same box test, leaf = primitives[primitivesOffset] only (the reference's leaf loop never
-// adds i; re-testing the same triangle primitiveCount times leaves the payload unchanged after the first test, so it
-// is tested once here).  FINITE selects the box-test form; the caller picks it per wave.
+template <bool FINITE>
+__device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray& ray, float ix,
+                                         float iy, float iz, bool nx, bool ny, bool nz) {
+  return FINITE ? box_test_finite(lox, loy, loz, hix, hiy, hiz, ray, ix, iy, iz)
+                : box_test_reference(lox, loy, loz, hix, hiy, hiz, ray, ix, iy, iz, nx, ny, nz);
+}
+
 #ifndef LT_TRI_BATCH
 #define LT_TRI_BATCH 16     // run the deferred triangle test when this many lanes hold a leaf (or when one must flush)
 #endif
@@ -249,8 +253,11 @@ __device__ __forceinline__ bool box_test_finite(const float4 a, const float4 b, 
 //    payload (no clipping against payload.t, acc.cl:113-130), and a lane still tests its leaves in reference order;
 //  * the top of the stack is kept in a register (`tos`), LDS holds the entries below it: a pop needs no LDS
 //    round trip before the next node's address is known (the reload of `tos` is off the critical path).
-template <int PROGRAM, bool DEEP, bool STATS, bool FINITE>
-__device__ inline void traverse_impl(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool useIgnore, int ignore,
+// ANYHIT (shadow rays, only when not counting work): the callers of a shadow ray read nothing but `hitType == 0`
+// (acc.cl:276, gi.cl:295,:351), so the walk may stop at the first accepted triangle -- same pixels, fewer node visits
+// than the reference algorithm performs.  The counting (STATS) instantiations never use it.
+template <int PROGRAM, bool DEEP, bool STATS, bool FINITE, bool ANYHIT>
+__device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool useIgnore, int ignore,
                                      Hit& pl, Stack<DEEP>& st, Counters& c) {
   const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
   const int ign = useIgnore ? ignore : -1;   // leaf offsets are >= 0
@@ -263,7 +270,7 @@ __device__ inline void traverse_impl(const SceneDev& sc, const Ray& ray, float i
     const float4 a = n[0], b = n[1];   // a = min.x min.y min.z max.x ; b = max.y max.z offset count|axis<<16
     if (STATS) c.nodes++;
     LT_WAVE_COUNT(wInner);
-    const bool hit = FINITE ? box_test_finite(a, b, ray, ix, iy, iz) : box_test_reference(a, b, ray, ix, iy, iz, nx, ny, nz);
+    const bool hit = box_test<FINITE>(a.x, a.y, a.z, a.w, b.x, b.y, ray, ix, iy, iz, nx, ny, nz);
     const uint32_t meta = __float_as_uint(b.w);
     const int off = __float_as_int(b.z);
     const uint32_t count = meta & 0xffffu;
@@ -277,6 +284,7 @@ __device__ inline void traverse_impl(const SceneDev& sc, const Ray& ray, float i
       if (intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl)) {
         pl.prim = pend;
         pl.hitType = 1;
+        if (ANYHIT) return;
       }
       pend = -1;
     }
@@ -311,9 +319,18 @@ __device__ inline void traverse_impl(const SceneDev& sc, const Ray& ray, float i
   }
 }
 
-template <int PROGRAM, bool DEEP, bool STATS>
+// Compile-time configuration of one kernel instantiation.
+template <bool DEEP_, bool STATS_, bool DEVLIBM_>
+struct Config {
+  static constexpr bool kDeep = DEEP_;       // BVH deeper than the LDS stack: spill entries >= kLdsStack to scratch
+  static constexpr bool kStats = STATS_;     // count rays / node visits / triangle tests
+  static constexpr bool kDevLibm = DEVLIBM_; // device-library leaf math (Math<true>)
+};
+
+template <int PROGRAM, bool DEEP, bool STATS, bool SHADOW = false>
 __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgnore, int ignore, Hit& pl,
                                 Stack<DEEP>& st, Counters& c) {
+  constexpr bool ANYHIT = SHADOW && !STATS;
   if (STATS) c.rays++;
   const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;   // (float)(1.0/(double)x) == 1.0f/x
   // |x| < inf is false for NaN and for +-inf
@@ -321,9 +338,9 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
                       __builtin_fabsf(iz) < __builtin_inff() && __builtin_fabsf(ray.o.x) < __builtin_inff() &&
                       __builtin_fabsf(ray.o.y) < __builtin_inff() && __builtin_fabsf(ray.o.z) < __builtin_inff();
   if (__all(finite)) {
-    traverse_impl<PROGRAM, DEEP, STATS, true>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
+    traverse_nodes_impl<PROGRAM, DEEP, STATS, true, ANYHIT>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
   } else {   // e.g. the image-centre column/row, where a direction component is exactly 0
-    traverse_impl<PROGRAM, DEEP, STATS, false>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
+    traverse_nodes_impl<PROGRAM, DEEP, STATS, false, ANYHIT>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
   }
 }
 
@@ -355,10 +372,10 @@ __device__ __forceinline__ const float* light_prim(const SceneDev& sc, float rnd
 
 // Light sample + shadow ray: acc.cl:239-279, basic_lighting.cl:234-274, gi.cl:267-297 and :323-349.
 // normal_w is 0 in accumulator/basic_lighting, 1 in GI (extractDataFromBarycentrics returns w = 1, gi.cl:238).
-template <int PROGRAM, bool DEEP, bool STATS, bool DEVLIBM>
+template <int PROGRAM, class CFG>
 __device__ inline bool direct_light(const SceneDev& sc, const float* pr, int primIndex, float u, float v, float fx,
                                     float fy, float seedIndex, float seedU, float seedV, float normal_w, V4& position,
-                                    V4& normal, float& ndotl, Stack<DEEP>& st, Counters& c) {
+                                    V4& normal, float& ndotl, Stack<CFG::kDeep>& st, Counters& c) {
   const V3 b = barycentrics(u, v);
   const V3 p3 = bary3(pr + 0, pr + 3, pr + 6, b);
   position = mk4(p3.x, p3.y, p3.z, 1.0f);
@@ -376,11 +393,11 @@ __device__ inline bool direct_light(const SceneDev& sc, const float* pr, int pri
   const V3 l3 = bary3(lp + 0, lp + 3, lp + 6, lb);
   const V4 lightPosition = mk4(l3.x, l3.y, l3.z, 1.0f);
 
-  const V4 toLight = normalize4<DEVLIBM>(sub4(lightPosition, position));
-  Hit spl{0, 0, (float)((double)distance4<DEVLIBM>(position, lightPosition) - 0.01), 0.0f, 0.0f};
+  const V4 toLight = normalize4<CFG::kDevLibm>(sub4(lightPosition, position));
+  Hit spl{0, 0, (float)((double)distance4<CFG::kDevLibm>(position, lightPosition) - 0.01), 0.0f, 0.0f};
   const Ray shadowRay{position, toLight};
-  if (STATS) c.shadow++;
-  traverse<PROGRAM, DEEP, STATS>(sc, shadowRay, true, primIndex, spl, st, c);
+  if (CFG::kStats) c.shadow++;
+  traverse<PROGRAM, CFG::kDeep, CFG::kStats, true>(sc, shadowRay, true, primIndex, spl, st, c);
   ndotl = dot4(toLight, normal);
   return spl.hitType == 0;
 }
@@ -395,8 +412,8 @@ __device__ inline V4 refract_(V4 I, V4 N, float firstIOR, float secondIOR) {
 }
 
 // basic.cl:225-277
-template <bool DEEP, bool STATS>
-__device__ inline void trace_ray_through_lens(const SceneDev& sc, Hit& pl, Ray& ray, Stack<DEEP>& st, Counters& c) {
+template <class CFG>
+__device__ inline void trace_ray_through_lens(const SceneDev& sc, Hit& pl, Ray& ray, Stack<CFG::kDeep>& st, Counters& c) {
   const float* pr = prim_ptr(sc, pl.prim);
   const Material* m = sc.mats + prim_material(pr);
   V3 b = barycentrics(pl.u, pl.v);
@@ -408,7 +425,7 @@ __device__ inline void trace_ray_through_lens(const SceneDev& sc, Hit& pl, Ray& 
 
   Hit pl2{0, 0, kFltMax, 0.0f, 0.0f};
   const Ray ray2{position, tdir};
-  traverse<kBasic, DEEP, STATS>(sc, ray2, true, pl.prim, pl2, st, c);
+  traverse<kBasic, CFG::kDeep, CFG::kStats>(sc, ray2, true, pl.prim, pl2, st, c);
 
   pr = prim_ptr(sc, pl2.prim);
   m = sc.mats + prim_material(pr);
@@ -422,20 +439,20 @@ __device__ inline void trace_ray_through_lens(const SceneDev& sc, Hit& pl, Ray& 
   pl = Hit{0, 0, kFltMax, 0.0f, 0.0f};
   ray.o = position;
   ray.d = tdir;
-  traverse<kBasic, DEEP, STATS>(sc, ray, true, pl2.prim, pl, st, c);
+  traverse<kBasic, CFG::kDeep, CFG::kStats>(sc, ray, true, pl2.prim, pl, st, c);
 }
 
 // basic.cl:279-307
-template <bool DEEP, bool STATS>
-__device__ inline V3 shade_basic(const SceneDev& sc, Ray ray, Stack<DEEP>& st, Counters& c) {
+template <class CFG>
+__device__ inline V3 shade_basic(const SceneDev& sc, Ray ray, Stack<CFG::kDeep>& st, Counters& c) {
   V3 out{0.0f, 0.0f, 0.0f};
   Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
-  traverse<kBasic, DEEP, STATS>(sc, ray, false, 0, pl, st, c);
+  traverse<kBasic, CFG::kDeep, CFG::kStats>(sc, ray, false, 0, pl, st, c);
   if (pl.hitType == 1) {
     const float* pr = prim_ptr(sc, pl.prim);
     const Material* m = sc.mats + prim_material(pr);
     if ((double)m->dissolve < 1.0) {
-      trace_ray_through_lens<DEEP, STATS>(sc, pl, ray, st, c);
+      trace_ray_through_lens<CFG>(sc, pl, ray, st, c);
       if (pl.hitType == 1) {
         pr = prim_ptr(sc, pl.prim);
         m = sc.mats + prim_material(pr);
@@ -447,12 +464,12 @@ __device__ inline V3 shade_basic(const SceneDev& sc, Ray ray, Stack<DEEP>& st, C
 }
 
 // acc.cl:219-282 / basic_lighting.cl:220-277
-template <int PROGRAM, bool DEEP, bool STATS, bool DEVLIBM>
+template <int PROGRAM, class CFG>
 __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, float fx, float fy, uint32_t s,
-                                    Stack<DEEP>& st, Counters& c) {
+                                    Stack<CFG::kDeep>& st, Counters& c) {
   V3 out{0.0f, 0.0f, 0.0f};
   Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
-  traverse<PROGRAM, DEEP, STATS>(sc, cameraRay, false, 0, pl, st, c);
+  traverse<PROGRAM, CFG::kDeep, CFG::kStats>(sc, cameraRay, false, 0, pl, st, c);
   if (PROGRAM == kAccumulator) {
     if (is_light(sc.lights, pl.prim)) return V3{1.0f, 1.0f, 1.0f};
   }
@@ -461,7 +478,7 @@ __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, fl
     const Material* m = sc.mats + prim_material(pr);
     V4 position, normal;
     float ndotl;
-    if (direct_light<PROGRAM, DEEP, STATS, DEVLIBM>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u),
+    if (direct_light<PROGRAM, CFG>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u),
                                            0.0f, position, normal, ndotl, st, c)) {
       out = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
     }
@@ -486,12 +503,12 @@ __device__ inline V4 align_hemisphere(V4 h, V4 up) {
 }
 
 // gi.cl:241-375
-template <bool DEEP, bool STATS, bool DEVLIBM>
+template <class CFG>
 __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx, float fy, uint32_t s, int maxDepth,
-                              Stack<DEEP>& st, Counters& c) {
+                              Stack<CFG::kDeep>& st, Counters& c) {
   V3 direct{0.0f, 0.0f, 0.0f}, indirect{0.0f, 0.0f, 0.0f};
   Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
-  traverse<kGI, DEEP, STATS>(sc, cameraRay, false, 0, pl, st, c);
+  traverse<kGI, CFG::kDeep, CFG::kStats>(sc, cameraRay, false, 0, pl, st, c);
   if (is_light(sc.lights, pl.prim)) {
     direct = V3{1.0f, 1.0f, 1.0f};
   } else if (pl.hitType == 1) {
@@ -499,18 +516,18 @@ __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx
     const Material* m = sc.mats + prim_material(pr);
     V4 position, normal;
     float ndotl;
-    if (direct_light<kGI, DEEP, STATS, DEVLIBM>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u), 1.0f,
+    if (direct_light<kGI, CFG>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u), 1.0f,
                                        position, normal, ndotl, st, c)) {
       direct = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
     }
-    V4 hemi = uniform_sample_hemisphere<DEVLIBM>(random_(fx, fy, (float)(s + 3u)), random_(fx, fy, (float)(s + 4u)));
-    Ray ext{position, align_hemisphere<DEVLIBM>(hemi, normal)};
+    V4 hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_(fx, fy, (float)(s + 3u)), random_(fx, fy, (float)(s + 4u)));
+    Ray ext{position, align_hemisphere<CFG::kDevLibm>(hemi, normal)};
     V4 previousNormal = normal;
     int previousPrimitive = pl.prim;
     bool rayActive = true;
     for (int d = 0; d < maxDepth && rayActive; d++) {
       Hit epl{0, 0, kFltMax, 0.0f, 0.0f};
-      traverse<kGI, DEEP, STATS>(sc, ext, true, previousPrimitive, epl, st, c);
+      traverse<kGI, CFG::kDeep, CFG::kStats>(sc, ext, true, previousPrimitive, epl, st, c);
       const float w = (float)(1.0 / (double)(d + 1));
       const uint32_t sd = s + (uint32_t)d;
       if (is_light(sc.lights, epl.prim)) {
@@ -524,14 +541,14 @@ __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx
         const Material* em = sc.mats + prim_material(epr);
         V4 epos, enorm;
         float endotl;
-        if (direct_light<kGI, DEEP, STATS, DEVLIBM>(sc, epr, epl.prim, epl.u, epl.v, fx, fy, (float)(sd + 5u), (float)(sd + 6u),
+        if (direct_light<kGI, CFG>(sc, epr, epl.prim, epl.u, epl.v, fx, fy, (float)(sd + 5u), (float)(sd + 6u),
                                            (float)(sd + 7u), 1.0f, epos, enorm, endotl, st, c)) {
           indirect.x += (w * em->diffuse[0]) * endotl;
           indirect.y += (w * em->diffuse[1]) * endotl;
           indirect.z += (w * em->diffuse[2]) * endotl;
-          hemi = uniform_sample_hemisphere<DEVLIBM>(random_(fx, fy, (float)(sd + 8u)), random_(fx, fy, (float)(sd + 9u)));
+          hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_(fx, fy, (float)(sd + 8u)), random_(fx, fy, (float)(sd + 9u)));
           ext.o = epos;
-          ext.d = align_hemisphere<DEVLIBM>(hemi, enorm);
+          ext.d = align_hemisphere<CFG::kDevLibm>(hemi, enorm);
           previousNormal = enorm;
           previousPrimitive = epl.prim;
         } else {
@@ -584,23 +601,23 @@ __device__ __forceinline__ Ray camera_ray(const FrameParams& fp, int x, int y, f
 
 // The body of linearKernel / tileKernel for one pixel, all five programs
 // (acc.cl:314-318, basic.cl:338-342, basic_lighting.cl:309-321, resources gi :408-420).
-template <int PROGRAM, bool DEEP, bool STATS, bool DEVLIBM>
-__device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int x, int y, Stack<DEEP>& st, Counters& c) {
+template <int PROGRAM, class CFG>
+__device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int x, int y, Stack<CFG::kDeep>& st, Counters& c) {
   float fx, fy;
-  const Ray ray = camera_ray<DEVLIBM>(fp, x, y, fx, fy);
+  const Ray ray = camera_ray<CFG::kDevLibm>(fp, x, y, fx, fy);
   V3 color;
   if (PROGRAM == kBasic) {
-    color = shade_basic<DEEP, STATS>(sc, ray, st, c);
+    color = shade_basic<CFG>(sc, ray, st, c);
   } else if (PROGRAM == kAccumulator) {
-    color = shade_lighting<kAccumulator, DEEP, STATS, DEVLIBM>(sc, ray, fx, fy, fp.frameCount, st, c);
+    color = shade_lighting<kAccumulator, CFG>(sc, ray, fx, fy, fp.frameCount, st, c);
   } else if (PROGRAM == kGI) {
-    color = shade_gi<DEEP, STATS, DEVLIBM>(sc, ray, fx, fy, fp.frameCount, fp.giMaxDepth, st, c);
+    color = shade_gi<CFG>(sc, ray, fx, fy, fp.frameCount, fp.giMaxDepth, st, c);
   } else {
     const uint32_t base = fp.frameCount * 32u;
     for (int k = 0; k < 25; k++) {
       const V3 cn = (PROGRAM == kBasicLighting)
-                        ? shade_lighting<kBasicLighting, DEEP, STATS, DEVLIBM>(sc, ray, fx, fy, base + (uint32_t)k, st, c)
-                        : shade_gi<DEEP, STATS, DEVLIBM>(sc, ray, fx, fy, base + (uint32_t)k, fp.giMaxDepth, st, c);
+                        ? shade_lighting<kBasicLighting, CFG>(sc, ray, fx, fy, base + (uint32_t)k, st, c)
+                        : shade_gi<CFG>(sc, ray, fx, fy, base + (uint32_t)k, fp.giMaxDepth, st, c);
       if (k == 0) {
         color = cn;
       } else {
@@ -610,7 +627,7 @@ __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int 
       }
     }
   }
-  if (PROGRAM != kBasic && fp.clampOutput) color = V3{Math<DEVLIBM>::clamp01(color.x), Math<DEVLIBM>::clamp01(color.y), Math<DEVLIBM>::clamp01(color.z)};
+  if (PROGRAM != kBasic && fp.clampOutput) color = V3{Math<CFG::kDevLibm>::clamp01(color.x), Math<CFG::kDevLibm>::clamp01(color.y), Math<CFG::kDevLibm>::clamp01(color.z)};
   return color;
 }
 
