@@ -31,6 +31,23 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
+def measured_traffic(workload_key):
+    """HBM bytes per launch of the dominant kernel from the PMC counters: they cannot be read from inside this process,
+    so tools/collect_profiles.sh collects FETCH_SIZE / WRITE_SIZE for this same command in separate rocprofv3 passes
+    and the summary is committed as profiles/<round>/hbm_traffic.json.  Returned only when it was measured on the same
+    workload; otherwise None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload", "").startswith(workload_key):
+            best = d.get("hbm_bytes_per_launch")
+    return best
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +81,7 @@ def main():
     import torch
     import torch.distributed as dist
     from lens_trace_amd import _capi as C
+    from lens_trace_amd.dist import TilePlan
     from lens_trace_amd.renderer import RendererHIP, make_desc
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -71,11 +89,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    # rehearsal knobs for a 1-GPU box: LT_BENCH_BACKEND=gloo LT_BENCH_SINGLE_DEVICE=1 runs N ranks on GPU 0 through gloo
+    backend = os.environ.get("LT_BENCH_BACKEND", "nccl")
+    if os.environ.get("LT_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     scene, scene_name = build_scene(args)
     scene.validate()
@@ -84,7 +109,8 @@ def main():
     r = RendererHIP(local_rank)
     r.set_scene(scene)
 
-    tile = (args.tile, args.tile, rank, world) if world > 1 else None
+    plan = TilePlan(W, H, D, args.tile, args.tile, world)
+    tile = plan.desc_tile(rank) if world > 1 else None
 
     def desc(stats=False):
         return make_desc(program, W, H, D, scene.camera, frame_first=1, frame_count=args.spp, accumulate=True, accumulate_base=0,
@@ -93,8 +119,8 @@ def main():
     d = desc()
     my_floats = r.output_floats(d)
     # every rank's stack is padded to the largest one so that the gather is uniform
-    tiles_x, tiles_y = (W + args.tile - 1) // args.tile, (H + args.tile - 1) // args.tile
-    per_rank = my_floats if world == 1 else ((tiles_x * tiles_y + world - 1) // world) * args.tile * args.tile * D
+    per_rank = my_floats if world == 1 else plan.floats_per_rank
+    assert my_floats <= per_rank
     mine = torch.zeros(per_rank, dtype=torch.float32, device=dev)
     gathered = [torch.empty(per_rank, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
     stack = torch.empty((world, per_rank), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
@@ -162,6 +188,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "note": "shadow rays stop at the first accepted hit (their callers read only hitType): same pixels, fewer node visits than "
+                    "the reference algorithm, whose counts (measured once with the counting kernel) price roofline.achieved",
             "config": {"workload": "%s, %d triangles, %dx%d, %d spp running mean, program %s, %s" % (
                            scene_name, scene.n_prims, W, H, args.spp, args.program,
                            "whole image on 1 GPU" if world == 1 else "%dx%d tiles interleaved over %d GPUs + 1 RCCL gather" % (args.tile, args.tile, world)),
@@ -170,7 +198,8 @@ def main():
                        "tri_tests_per_ray": tris_total / rays_total, "kernel_only_mrays_per_s": round(rays_total * args.steps / kernel_s / 1e6, 2),
                        "frame_ms": round(ms_per_step, 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": measured_traffic("%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program)) if world == 1 else None,
                          "kernel": "lt_render_kernel<accumulator>", "launch_ms": round(launch_ms, 4),
                          "algorithmic_bytes_per_launch": my_alg_bytes_per_launch},
         }
