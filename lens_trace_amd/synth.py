@@ -86,7 +86,7 @@ def blob_in_box(subdiv=5, camera=None):
     u = np.linspace(0.0, 2.0 * np.pi, nu + 1)
     v = np.linspace(1e-3, np.pi - 1e-3, nv + 1)
     U, V = np.meshgrid(u, v)
-    R = 1.6 + 0.18 * np.sin(5 * U) * np.sin(4 * V) + 0.07 * np.sin(13 * U + 3.0) * np.sin(11 * V)
+    R = 2.3 + 0.25 * np.sin(5 * U) * np.sin(4 * V) + 0.09 * np.sin(13 * U + 3.0) * np.sin(11 * V)
     P = np.stack([R * np.sin(V) * np.cos(U), 2.5 + R * np.cos(V), -2.5 + R * np.sin(V) * np.sin(U)], axis=-1)
     dU = np.gradient(P, axis=1)
     dV = np.gradient(P, axis=0)
@@ -98,16 +98,70 @@ def blob_in_box(subdiv=5, camera=None):
     def quad(a, b, c, d, n):
         quads.append((np.float32([[a, b, c], [a, c, d]]), np.tile(np.float32(n), (2, 3, 1))))
 
-    quad([-5, -2, -6], [5, -2, -6], [5, -2, 1], [-5, -2, 1], [0, 1, 0])        # floor
-    quad([-5, 7, -6], [5, 7, -6], [5, 7, 1], [-5, 7, 1], [0, -1, 0])           # ceiling
-    quad([-5, -2, 1], [5, -2, 1], [5, 7, 1], [-5, 7, 1], [0, 0, -1])           # back
-    quad([-5, -2, -6], [-5, -2, 1], [-5, 7, 1], [-5, 7, -6], [1, 0, 0])        # left
-    quad([5, -2, -6], [5, -2, 1], [5, 7, 1], [5, 7, -6], [-1, 0, 0])           # right
+    quad([-4.2, -1.8, -6], [4.2, -1.8, -6], [4.2, -1.8, 1], [-4.2, -1.8, 1], [0, 1, 0])        # floor
+    quad([-4.2, 6.8, -6], [4.2, 6.8, -6], [4.2, 6.8, 1], [-4.2, 6.8, 1], [0, -1, 0])           # ceiling
+    quad([-4.2, -1.8, 1], [4.2, -1.8, 1], [4.2, 6.8, 1], [-4.2, 6.8, 1], [0, 0, -1])           # back
+    quad([-4.2, -1.8, -6], [-4.2, -1.8, 1], [-4.2, 6.8, 1], [-4.2, 6.8, -6], [1, 0, 0])        # left
+    quad([4.2, -1.8, -6], [4.2, -1.8, 1], [4.2, 6.8, 1], [4.2, 6.8, -6], [-1, 0, 0])           # right
     wp = np.concatenate([q[0] for q in quads])
     wn = np.concatenate([q[1] for q in quads])
-    lp, ln = _light_quad(-1.0, 1.0, 6.9, -4.0, -2.0)
+    lp, ln = _light_quad(-1.0, 1.0, 6.7, -5.5, -4.0)
     mats = _materials([(0.8, 0.8, 0.8), (0.9, 0.3, 0.25), (0.3, 0.75, 0.35), (0.85, 0.75, 0.3)])
     mi = np.concatenate([np.full(pos.shape[0], 3, np.int32), np.int32([0, 0, 0, 0, 0, 0, 1, 1, 2, 2]),
                          np.full(2, len(mats) - 1, np.int32)])
     return build_from_triangles(np.concatenate([pos, wp, lp]), np.concatenate([nrm, wn, ln]), mi, mats,
                                 camera or camera_bytes(0.0, 2.5, -50.0))
+
+
+def colonnade(columns=14, segments=96, rings=40, camera=None):
+    """Config 5: a Sponza-like hall (~250 k triangles at the defaults): two rows of fluted columns carrying arches,
+    floor, back wall and ceiling strips, one 2-triangle light.  Closed form, no RNG."""
+    parts_p, parts_n, parts_m = [], [], []
+
+    def add_grid(P, N, mat):
+        p, n = _grid_triangles(P, N)
+        parts_p.append(p)
+        parts_n.append(n)
+        parts_m.append(np.full(p.shape[0], mat, np.int32))
+
+    # fluted columns: radius modulated by cos(16 theta), axis along y
+    th = np.linspace(0.0, 2.0 * np.pi, segments + 1)
+    yy = np.linspace(-2.0, 4.2, rings + 1)
+    TH, YY = np.meshgrid(th, yy)
+    for side in (-1.0, 1.0):
+        for k in range(columns // 2):
+            cx, cz = side * 2.6, -8.0 + k * (9.0 / max(1, columns // 2 - 1))
+            R = 0.32 + 0.025 * np.cos(16.0 * TH) + 0.05 * np.exp(-((YY + 1.7) / 0.25) ** 2) + 0.05 * np.exp(-((YY - 3.9) / 0.25) ** 2)
+            P = np.stack([cx + R * np.cos(TH), YY, cz + R * np.sin(TH)], axis=-1)
+            N = np.stack([np.cos(TH), np.zeros_like(TH), np.sin(TH)], axis=-1)
+            add_grid(P, N, 0 if k % 2 == 0 else 3)
+    # arches between consecutive columns of a row: half tori in the x = const planes
+    ph = np.linspace(0.0, np.pi, 48 + 1)
+    ps = np.linspace(0.0, 2.0 * np.pi, 24 + 1)
+    PH, PS = np.meshgrid(ph, ps)
+    step = 9.0 / max(1, columns // 2 - 1)
+    for side in (-1.0, 1.0):
+        for k in range(columns // 2 - 1):
+            cx, cz = side * 2.6, -8.0 + (k + 0.5) * step
+            Rm, rt = step / 2.0, 0.22
+            P = np.stack([cx + rt * np.cos(PS), 4.2 + (Rm + rt * np.sin(PS)) * np.sin(PH), cz + (Rm + rt * np.sin(PS)) * np.cos(PH)], axis=-1)
+            N = np.stack([np.cos(PS), np.sin(PS) * np.sin(PH), np.sin(PS) * np.cos(PH)], axis=-1)
+            add_grid(P, N, 1)
+    # floor (finely tessellated with a gentle ripple), back wall, ceiling strip
+    gx = np.linspace(-5.0, 5.0, 200 + 1)
+    gz = np.linspace(-10.0, 2.0, 200 + 1)
+    GX, GZ = np.meshgrid(gx, gz)
+    GY = -2.0 + 0.02 * np.sin(3.0 * GX) * np.sin(2.0 * GZ)
+    Nf = np.stack([-0.06 * np.cos(3.0 * GX) * np.sin(2.0 * GZ), np.ones_like(GX), -0.04 * np.sin(3.0 * GX) * np.cos(2.0 * GZ)], axis=-1)
+    Nf /= np.linalg.norm(Nf, axis=-1, keepdims=True)
+    add_grid(np.stack([GX, GY, GZ], axis=-1), Nf, 2)
+    wy = np.linspace(-2.0, 7.5, 60 + 1)
+    WX, WY = np.meshgrid(gx, wy)
+    add_grid(np.stack([WX, WY, np.full_like(WX, 2.0)], axis=-1), np.tile(np.float64([0, 0, -1]), WX.shape + (1,)), 0)
+    add_grid(np.stack([GX[:40], np.full_like(GX[:40], 7.5), GZ[:40] * 0.3 - 1.0], axis=-1), np.tile(np.float64([0, -1, 0]), GX[:40].shape + (1,)), 3)
+    lp, ln = _light_quad(-1.2, 1.2, 7.2, -6.0, -4.0)
+    mats = _materials([(0.8, 0.78, 0.7), (0.75, 0.45, 0.3), (0.55, 0.55, 0.6), (0.7, 0.7, 0.75)])
+    pos = np.concatenate(parts_p + [lp])
+    nrm = np.concatenate(parts_n + [ln])
+    mi = np.concatenate(parts_m + [np.full(2, len(mats) - 1, np.int32)])
+    return build_from_triangles(pos, nrm, mi, mats, camera or camera_bytes(0.0, 2.5, -50.0))
