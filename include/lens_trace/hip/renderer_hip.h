@@ -48,6 +48,9 @@ class RendererHIP final : public Renderer {
   ~RendererHIP();
   void render(void* pRenderProperties);
   bool isValid() const { return context != nullptr; }
+  // Scene buffers are uploaded once and reused while render() keeps receiving the same buffers (same addresses, sizes
+  // and content fingerprint).  Call this after modifying a scene buffer in place.
+  void invalidateScene();
   const char* getLastError() const;
 
  private:
@@ -56,4 +59,5 @@ class RendererHIP final : public Renderer {
   // caller hands over different objects or buffers
   const void* cachedKey[4];
   uint64_t cachedSize[4];
+  uint64_t cachedFingerprint;
 };

@@ -9,11 +9,30 @@
 
 #include "lenstrace_hip.h"
 
+// 64-bit FNV-1a over the sizes and a strided sample of the four scene buffers: cheap (a few KB per call), and enough to
+// tell a different scene that reuses the same addresses from the cached one.
+static uint64_t sceneFingerprint(const void* const* buf, const uint64_t* size) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&h](const unsigned char* p, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+  };
+  for (int b = 0; b < 4; b++) {
+    const unsigned char* p = (const unsigned char*)buf[b];
+    const uint64_t n = size[b];
+    mix((const unsigned char*)&n, sizeof(n));
+    const uint64_t step = n / 4096 + 1;
+    for (uint64_t i = 0; i + 8 <= n; i += step * 8) mix(p + i, 8);
+    mix(p + (n > 256 ? n - 256 : 0), n > 256 ? 256 : n);
+  }
+  return h;
+}
+
 RendererHIP::RendererHIP() : RendererHIP(0) {}
 
 RendererHIP::RendererHIP(int deviceIndex) : context(nullptr) {
   memset(cachedKey, 0, sizeof(cachedKey));
   memset(cachedSize, 0, sizeof(cachedSize));
+  cachedFingerprint = 0;
   if (lt_hip_create(deviceIndex, &context) != LT_OK) {
     printf("ERROR: RendererHIP: %s\n", lt_hip_last_error(nullptr));
     context = nullptr;
@@ -23,6 +42,8 @@ RendererHIP::RendererHIP(int deviceIndex) : context(nullptr) {
 RendererHIP::~RendererHIP() { lt_hip_destroy(context); }
 
 const char* RendererHIP::getLastError() const { return lt_hip_last_error(context); }
+
+void RendererHIP::invalidateScene() { memset(cachedKey, 0, sizeof(cachedKey)); }
 
 void RendererHIP::render(void* pRenderProperties) {
   RenderPropertiesHIP* props = (RenderPropertiesHIP*)pRenderProperties;
@@ -51,7 +72,8 @@ void RendererHIP::render(void* pRenderProperties) {
                         pAS->getLightContainerBuffer()};
   const uint64_t size[4] = {pAS->getNodeBufferSize(), pAS->getOrderedPrimitiveBufferSize(), pModel->getMaterialBufferSize(),
                             pAS->getLightContainerBufferSize()};
-  if (memcmp(key, cachedKey, sizeof(key)) != 0 || memcmp(size, cachedSize, sizeof(size)) != 0) {
+  const uint64_t fingerprint = sceneFingerprint(key, size);
+  if (memcmp(key, cachedKey, sizeof(key)) != 0 || memcmp(size, cachedSize, sizeof(size)) != 0 || fingerprint != cachedFingerprint) {
     if (lt_hip_set_scene(context, key[0], size[0], key[1], size[1], key[2], size[2], key[3], size[3]) != LT_OK) {
       printf("Kernel Error: %s\n", lt_hip_last_error(context));
       memset(cachedKey, 0, sizeof(cachedKey));
@@ -59,6 +81,7 @@ void RendererHIP::render(void* pRenderProperties) {
     }
     memcpy(cachedKey, key, sizeof(key));
     memcpy(cachedSize, size, sizeof(size));
+    cachedFingerprint = fingerprint;
   }
 
   lt_hip_render_desc desc;

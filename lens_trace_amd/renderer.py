@@ -64,6 +64,17 @@ def make_desc(program, W, H, depth, camera28, kernel_mode=KERNEL_MODE_LINEAR, fr
     return d
 
 
+def _fingerprint(arrays):
+    """Cheap content fingerprint of the scene buffers (sizes + a strided sample), so that a different scene that happens to
+    reuse an object id or an address is not mistaken for the cached one."""
+    h = []
+    for a in arrays:
+        b = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        step = max(1, b.size // 4096)
+        h.append((b.size, hash(b[::step].tobytes()), hash(b[:256].tobytes()), hash(b[-256:].tobytes())))
+    return tuple(h)
+
+
 class RendererHIP:
     """One context per GPU.  `device` is the HIP ordinal."""
 
@@ -74,6 +85,7 @@ class RendererHIP:
         if rc:
             raise C.LensTraceError(rc, self._L.lt_hip_last_error(None).decode())
         self._scene_key = None
+        self._scene_refs = None
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -98,7 +110,14 @@ class RendererHIP:
         for a in arrs:
             args += [a.ctypes.data_as(ctypes.c_void_p), a.nbytes]
         self._check(self._L.lt_hip_set_scene(self._ctx, *args))
-        self._scene_key = (id(scene), id(materials or scene))
+        # the cache key is object identity: keep the objects alive so their ids cannot be recycled by a new scene
+        self._scene_refs = (scene, materials or scene)
+        self._scene_key = (id(scene), id(materials or scene), _fingerprint(arrs))
+
+    def invalidate_scene(self):
+        """Forget the uploaded scene (call after modifying scene buffers in place)."""
+        self._scene_key = None
+        self._scene_refs = None
 
     # -- the plugin entry point ----------------------------------------------------------------------
     def render(self, props: RenderPropertiesHIP):
@@ -106,9 +125,11 @@ class RendererHIP:
         out = props.pOutputBuffer
         if out.dtype != np.float32 or not out.flags.c_contiguous:
             raise ValueError("pOutputBuffer must be contiguous float32")
-        key = (id(props.pAccelerationStructureExplicit), id(props.pModel or props.pAccelerationStructureExplicit))
-        if key != self._scene_key:      # the reference re-uploads on every call; here it is cached by identity
-            self.set_scene(props.pAccelerationStructureExplicit, props.pModel)
+        a = props.pAccelerationStructureExplicit
+        m = props.pModel or a
+        key = (id(a), id(m), _fingerprint([a.nodes, a.prims, m.materials, a.lights]))
+        if key != self._scene_key:      # the reference re-uploads on every call; here the upload is cached
+            self.set_scene(a, props.pModel)
         program = C.program_from_path(props.kernelFilePath)
         d = make_desc(program, W, H, D, props.pCamera, props.kernelMode, props.frameFirst, props.frameCount,
                       props.accumulate, props.accumulateBase, None, props.giMaxDepth, props.collectStats, props.pixelCounters, props.deviceLibm)
