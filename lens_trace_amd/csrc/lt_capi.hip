@@ -254,7 +254,7 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
   if (node_bytes == 0 || node_bytes % 32 || prim_bytes == 0 || prim_bytes % 76 || material_bytes == 0 || material_bytes % 32 ||
       light_bytes != 260)
     return fail(ctx, LT_ERR_BAD_SCENE, "scene buffer sizes are not whole multiples of LinearBVHNode(32) / Primitive(76) / Material(32) / LightContainer(260)");
-  if (node_bytes / 32 > 0x7fffffffull || prim_bytes / 76 > 0x7fffffffull) return fail(ctx, LT_ERR_BAD_SCENE, "scene too large for int32 indices");
+  if (node_bytes > 0xffffffffull || prim_bytes / 76 > 0x7fffffffull / 48) return fail(ctx, LT_ERR_BAD_SCENE, "scene too large for 32-bit byte offsets (4 GiB of nodes / 2 GiB of traversal triangles)");
   const uint32_t n_nodes = (uint32_t)(node_bytes / 32), n_prims = (uint32_t)(prim_bytes / 76), n_mats = (uint32_t)(material_bytes / 32);
   std::string msg;
   const int height = validate_scene((const uint8_t*)nodes, n_nodes, (const uint8_t*)prims, n_prims, n_mats, (const uint8_t*)lights, msg);
@@ -397,8 +397,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       fp.frameCount = d->frame_count ? d->frame_first + f : camFrame;
       fp.accumulateN = (d->frame_count && d->accumulate) ? (int32_t)(d->accumulate_base + f) : -1;
       const dim3 grid((uint32_t)nblocks);
-      // LDS stack rows: the traversal stack never holds more entries than the BVH has interior levels
-      uint32_t lds = (uint32_t)std::min(ctx->bvh_height + 1, kLdsStack) * kBlock * sizeof(int);
+      // LDS stack rows: with the top entry in a register, the rows below it number at most (interior levels - 1)
+      uint32_t lds = (uint32_t)std::max(1, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
       switch (d->program) {
         case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;

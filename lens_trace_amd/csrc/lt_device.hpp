@@ -150,9 +150,7 @@ __device__ inline float random_(float uvx, float uvy, float seed) {
 // acc.cl:72-111 on the re-tiled triangle.  PROGRAM picks the epsilon flavour: basic.cl:78 compares in
 // float against 1e-7f, basic_lighting.cl:4 in double against 1e-7, the others in double against 1e-4.
 template <int PROGRAM>
-__device__ __forceinline__ bool intersect_triangle(const float4* __restrict__ tris, int prim, const Ray& ray, Hit& pl) {
-  const float4* t = tris + 3 * (size_t)prim;
-  float4 t0 = t[0], t1 = t[1], t2 = t[2];
+__device__ __forceinline__ bool intersect_triangle_data(const float4 t0, const float4 t1, const float4 t2, const Ray& ray, Hit& pl) {
   V4 A = mk4(t0.x, t0.y, t0.z, 1.0f);
   V4 v0v1 = mk4(t0.w, t1.x, t1.y, 0.0f);
   V4 v0v2 = mk4(t1.z, t1.w, t2.x, 0.0f);
@@ -178,6 +176,12 @@ __device__ __forceinline__ bool intersect_triangle(const float4* __restrict__ tr
     return true;
   }
   return false;
+}
+
+template <int PROGRAM>
+__device__ __forceinline__ bool intersect_triangle(const float4* __restrict__ tris, int prim, const Ray& ray, Hit& pl) {
+  const float4* t = tris + 3 * (size_t)prim;
+  return intersect_triangle_data<PROGRAM>(t[0], t[1], t[2], ray, pl);
 }
 
 // The per-lane traversal stack: entries [0,kLdsStack) live in LDS (column `lane`, row stride kBlock, so
@@ -266,7 +270,9 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
   uint32_t pendCount = 0;
   bool alive = true;
   while (alive) {
-    const float4* n = sc.nodes + 2 * (size_t)cur;
+    // 32-bit byte offset from the (wave-uniform) array base: lets the load use the SGPR-base + VGPR-offset form instead of
+    // 64-bit address arithmetic on the node-to-node dependency chain (n_nodes * 32 < 2^32 is checked at set_scene)
+    const float4* n = (const float4*)((const char*)sc.nodes + ((uint32_t)cur << 5));
     const float4 a = n[0], b = n[1];   // a = min.x min.y min.z max.x ; b = max.y max.z offset count|axis<<16
     if (STATS) c.nodes++;
     LT_WAVE_COUNT(wInner);
@@ -327,7 +333,108 @@ struct Config {
   static constexpr bool kDevLibm = DEVLIBM_; // device-library leaf math (Math<true>)
 };
 
-template <int PROGRAM, bool DEEP, bool STATS, bool SHADOW = false>
+template <int PROGRAM, bool DEEP, bool STATS, bool SHADOW>
+__device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgnore, int ignore, Hit& pl, Stack<DEEP>& st, Counters& c);
+
+// ---------------------------------------------------------------- packet traversal (camera rays)
+// The 64 camera rays of a wavefront (an 8x8 pixel square) visit almost the same nodes: on the 1 M-triangle scene at 4K
+// the union of their visited sets is 160 nodes against ~150 for any single ray.  When all of them are finite and share
+// their direction signs (every wave except those on the image's centre column/row) the wave walks the tree ONCE:
+//  * the node is fetched with scalar loads (one 32-byte s_load through the scalar cache instead of 64 lanes x 2 vector
+//    loads) and lands in SGPRs; each lane runs the same slab test against its own ray;
+//  * a lane "visits" a node iff it hit every ancestor's box -- a 64-bit lane mask travels with the node index on a
+//    wave-uniform stack (three dwords in the wave's LDS row) -- so each lane's set of tested nodes, the order in which it
+//    meets its leaves (near child first by the shared direction signs) and its work counters are exactly those of its own
+//    reference traversal; the wave descends while any lane hits;
+//  * no per-lane stack, no divergence inside the walk; the triangle test runs for the lanes that hit the leaf's box.
+typedef float F4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) F4v* ConstF4;   // constant address space: uniform loads become s_load
+__device__ __forceinline__ float4 ld_const(ConstF4 p) { const F4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
+
+template <int PROGRAM, bool STATS>
+__device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool nxU, bool nyU, bool nzU,
+                                       Hit& pl, int* ldsWave, Counters& c) {
+  using u64 = unsigned long long;
+  const ConstF4 nodes = (ConstF4)(uintptr_t)sc.nodes;
+  const ConstF4 tris = (ConstF4)(uintptr_t)sc.tris;
+  const int lane = (int)__lane_id();
+  u64 mask = __ballot(1);
+  const int leader = __ffsll((long long)mask) - 1;
+  int cur = 0, sp = 0;
+  for (;;) {
+    const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane(cur);
+    const float4 a = ld_const(nodes + 2 * (size_t)ci), b = ld_const(nodes + 2 * (size_t)ci + 1);
+    const bool in = (mask >> lane) & 1ull;
+    if (STATS && in) c.nodes++;
+#ifdef LT_DEBUG_WAVE_COUNTERS
+    if (lane == 0) c.wInner++;
+    if (in) c.wOuter++;
+#endif
+    const bool hit = in && box_test_finite(a.x, a.y, a.z, a.w, b.x, b.y, ray, ix, iy, iz);
+    const u64 hmask = __ballot(hit);
+    const uint32_t meta = __float_as_uint(b.w);
+    const int off = __float_as_int(b.z);
+    const uint32_t count = meta & 0xffffu;
+    if (hmask != 0ull && count == 0u) {
+      const uint32_t axis = (meta >> 16) & 0xffu;
+      const bool neg = axis == 0 ? nxU : (axis == 1 ? nyU : nzU);
+      const int farChild = neg ? (int)ci + 1 : off;
+      if (lane == leader) {   // any lane may be switched off (image edge): the first active one writes the entry
+        ldsWave[sp * kBlock + 0] = farChild;
+        ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmask;
+        ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmask >> 32);
+      }
+      sp++;
+      cur = neg ? off : (int)ci + 1;
+      mask = hmask;
+      continue;
+    }
+    if (hmask != 0ull) {   // leaf whose box some lanes hit
+#ifdef LT_DEBUG_WAVE_COUNTERS
+      if (lane == 0) c.wTri++;
+#endif
+      if (hit) {
+        if (STATS) c.tris += count;    // the reference *calls* intersectTriangle primitiveCount times
+        const ConstF4 t = tris + 3 * (size_t)(uint32_t)off;
+        const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
+        if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl)) {
+          pl.prim = off;
+          pl.hitType = 1;
+        }
+      }
+    }
+    if (sp == 0) break;
+    sp--;
+    cur = __builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 0]);      // same address in every lane: broadcast reads
+    mask = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 1]) |
+           ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 2]) << 32);
+  }
+}
+
+// Camera rays: packet traversal when the wave qualifies, the per-lane traversal otherwise.
+template <int PROGRAM, bool DEEP, bool STATS>
+__device__ inline void traverse_camera(const SceneDev& sc, const Ray& ray, Hit& pl, Stack<DEEP>& st, Counters& c) {
+  const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
+  const bool finite = __builtin_fabsf(ix) < __builtin_inff() && __builtin_fabsf(iy) < __builtin_inff() &&
+                      __builtin_fabsf(iz) < __builtin_inff() && __builtin_fabsf(ray.o.x) < __builtin_inff() &&
+                      __builtin_fabsf(ray.o.y) < __builtin_inff() && __builtin_fabsf(ray.o.z) < __builtin_inff();
+  const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
+  const unsigned long long all = __ballot(1), bx = __ballot(nx), by = __ballot(ny), bz = __ballot(nz);
+  const bool uniformSigns = (bx == 0ull || bx == all) && (by == 0ull || by == all) && (bz == 0ull || bz == all);
+#ifndef LT_NO_PACKETS
+  constexpr bool kPackets = !DEEP;   // the wave-uniform stack shares the LDS rows, which cover BVH heights <= kLdsStack
+#else
+  constexpr bool kPackets = false;
+#endif
+  if (kPackets && __all(finite) && uniformSigns) {
+    if (STATS) c.rays++;
+    traverse_packet<PROGRAM, STATS>(sc, ray, ix, iy, iz, bx != 0ull, by != 0ull, bz != 0ull, pl, st.lds - __lane_id(), c);
+  } else {
+    traverse<PROGRAM, DEEP, STATS, false>(sc, ray, false, 0, pl, st, c);
+  }
+}
+
+template <int PROGRAM, bool DEEP, bool STATS, bool SHADOW>
 __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgnore, int ignore, Hit& pl,
                                 Stack<DEEP>& st, Counters& c) {
   constexpr bool ANYHIT = SHADOW && !STATS;
@@ -425,7 +532,7 @@ __device__ inline void trace_ray_through_lens(const SceneDev& sc, Hit& pl, Ray& 
 
   Hit pl2{0, 0, kFltMax, 0.0f, 0.0f};
   const Ray ray2{position, tdir};
-  traverse<kBasic, CFG::kDeep, CFG::kStats>(sc, ray2, true, pl.prim, pl2, st, c);
+  traverse<kBasic, CFG::kDeep, CFG::kStats, false>(sc, ray2, true, pl.prim, pl2, st, c);
 
   pr = prim_ptr(sc, pl2.prim);
   m = sc.mats + prim_material(pr);
@@ -439,7 +546,7 @@ __device__ inline void trace_ray_through_lens(const SceneDev& sc, Hit& pl, Ray& 
   pl = Hit{0, 0, kFltMax, 0.0f, 0.0f};
   ray.o = position;
   ray.d = tdir;
-  traverse<kBasic, CFG::kDeep, CFG::kStats>(sc, ray, true, pl2.prim, pl, st, c);
+  traverse<kBasic, CFG::kDeep, CFG::kStats, false>(sc, ray, true, pl2.prim, pl, st, c);
 }
 
 // basic.cl:279-307
@@ -447,7 +554,7 @@ template <class CFG>
 __device__ inline V3 shade_basic(const SceneDev& sc, Ray ray, Stack<CFG::kDeep>& st, Counters& c) {
   V3 out{0.0f, 0.0f, 0.0f};
   Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
-  traverse<kBasic, CFG::kDeep, CFG::kStats>(sc, ray, false, 0, pl, st, c);
+  traverse_camera<kBasic, CFG::kDeep, CFG::kStats>(sc, ray, pl, st, c);
   if (pl.hitType == 1) {
     const float* pr = prim_ptr(sc, pl.prim);
     const Material* m = sc.mats + prim_material(pr);
@@ -469,7 +576,7 @@ __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, fl
                                     Stack<CFG::kDeep>& st, Counters& c) {
   V3 out{0.0f, 0.0f, 0.0f};
   Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
-  traverse<PROGRAM, CFG::kDeep, CFG::kStats>(sc, cameraRay, false, 0, pl, st, c);
+  traverse_camera<PROGRAM, CFG::kDeep, CFG::kStats>(sc, cameraRay, pl, st, c);
   if (PROGRAM == kAccumulator) {
     if (is_light(sc.lights, pl.prim)) return V3{1.0f, 1.0f, 1.0f};
   }
@@ -508,7 +615,7 @@ __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx
                               Stack<CFG::kDeep>& st, Counters& c) {
   V3 direct{0.0f, 0.0f, 0.0f}, indirect{0.0f, 0.0f, 0.0f};
   Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
-  traverse<kGI, CFG::kDeep, CFG::kStats>(sc, cameraRay, false, 0, pl, st, c);
+  traverse_camera<kGI, CFG::kDeep, CFG::kStats>(sc, cameraRay, pl, st, c);
   if (is_light(sc.lights, pl.prim)) {
     direct = V3{1.0f, 1.0f, 1.0f};
   } else if (pl.hitType == 1) {
@@ -527,7 +634,7 @@ __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx
     bool rayActive = true;
     for (int d = 0; d < maxDepth && rayActive; d++) {
       Hit epl{0, 0, kFltMax, 0.0f, 0.0f};
-      traverse<kGI, CFG::kDeep, CFG::kStats>(sc, ext, true, previousPrimitive, epl, st, c);
+      traverse<kGI, CFG::kDeep, CFG::kStats, false>(sc, ext, true, previousPrimitive, epl, st, c);
       const float w = (float)(1.0 / (double)(d + 1));
       const uint32_t sd = s + (uint32_t)d;
       if (is_light(sc.lights, epl.prim)) {
