@@ -62,13 +62,14 @@ enum {
   LT_ERR_UNKNOWN_PROGRAM = 7
 };
 
-/* the five kernel files the reference ships, selected by kernelFilePath in RenderProperties* */
+/* the kernel files the reference ships (five renderer programs + the custom_kernel example's), selected by kernelFilePath in RenderProperties* */
 enum {
   LT_PROGRAM_BASIC = 0,                  /* resources/kernels/opencl/basic.cl */
   LT_PROGRAM_BASIC_LIGHTING = 1,         /* resources/kernels/opencl/basic_lighting.cl (25 blended samples) */
   LT_PROGRAM_ACCUMULATOR = 2,            /* examples/accumulator/resources/kernels/accumulator.cl */
   LT_PROGRAM_GLOBAL_ILLUMINATION = 3,    /* examples/global_illumination/resources/kernels/global_illumination.cl */
-  LT_PROGRAM_GLOBAL_ILLUMINATION_25 = 4  /* resources/kernels/opencl/global_illumination.cl (25 blended samples) */
+  LT_PROGRAM_GLOBAL_ILLUMINATION_25 = 4, /* resources/kernels/opencl/global_illumination.cl (25 blended samples) */
+  LT_PROGRAM_CUSTOM_OPENCL = 5           /* examples/custom_kernel/resources/kernels/custom_opencl.cl (barycentrics as colour) */
 };
 
 /* KernelMode of include/lens_trace/structures.h:20-23.  Pixels do not depend on it, except that the

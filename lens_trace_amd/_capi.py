@@ -12,6 +12,7 @@ STATUS_NAMES = ["LT_OK", "LT_ERR_INVALID_ARGUMENT", "LT_ERR_NO_DEVICE", "LT_ERR_
                 "LT_ERR_BAD_SCENE", "LT_ERR_BUFFER_TOO_SMALL", "LT_ERR_UNKNOWN_PROGRAM"]
 
 PROGRAM_BASIC, PROGRAM_BASIC_LIGHTING, PROGRAM_ACCUMULATOR, PROGRAM_GLOBAL_ILLUMINATION, PROGRAM_GLOBAL_ILLUMINATION_25 = range(5)
+PROGRAM_CUSTOM_OPENCL = 5
 KERNEL_MODE_LINEAR, KERNEL_MODE_TILE = 0, 1
 RENDER_FLAG_STATS = 1
 RENDER_FLAG_PIXEL_COUNTERS = 2

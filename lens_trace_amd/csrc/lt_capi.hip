@@ -194,6 +194,7 @@ extern "C" int lt_hip_program_from_path(const char* path, int* out_program) {
   if (base == "basic") *out_program = LT_PROGRAM_BASIC;
   else if (base == "basic_lighting") *out_program = LT_PROGRAM_BASIC_LIGHTING;
   else if (base == "accumulator") *out_program = LT_PROGRAM_ACCUMULATOR;
+  else if (base == "custom_opencl") *out_program = LT_PROGRAM_CUSTOM_OPENCL;
   else if (base == "global_illumination25") *out_program = LT_PROGRAM_GLOBAL_ILLUMINATION_25;
   else if (base == "global_illumination") {
     const bool shipped25 = p.find("resources/kernels/opencl/") != std::string::npos && p.find("examples/") == std::string::npos;
@@ -344,7 +345,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   std::string msg;
   int rc = plan_tiles(d, p, msg);
   if (rc) return fail(ctx, rc, msg);
-  if (d->program < LT_PROGRAM_BASIC || d->program > LT_PROGRAM_GLOBAL_ILLUMINATION_25) return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "unknown program");
+  if (d->program < LT_PROGRAM_BASIC || d->program > LT_PROGRAM_CUSTOM_OPENCL) return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "unknown program");
   if (d->kernel_mode != LT_KERNEL_MODE_LINEAR && d->kernel_mode != LT_KERNEL_MODE_TILE) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "unknown kernel mode");
   if (!out_device) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "output pointer is NULL");
   if (out_bytes < p.floats * sizeof(float)) return fail(ctx, LT_ERR_BUFFER_TOO_SMALL, "output buffer smaller than the image/tile stack");
@@ -405,7 +406,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
         case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
         case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
-        default: launch_program<kGI25>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        default: launch_program<kCustom>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
       }
       LT_HIP_CHECK(ctx, hipGetLastError());
       launches++;

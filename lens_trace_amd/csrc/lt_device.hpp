@@ -23,7 +23,7 @@ constexpr int kLdsStack = 32;      // most traversal-stack entries per lane held
 constexpr int kMaxStack = 64;      // the reference's nodesToVisit[64] (acc.cl:137)
 constexpr float kFltMax = 3.402823466e+38f;
 
-enum Program { kBasic = 0, kBasicLighting = 1, kAccumulator = 2, kGI = 3, kGI25 = 4 };
+enum Program { kBasic = 0, kBasicLighting = 1, kAccumulator = 2, kGI = 3, kGI25 = 4, kCustom = 5 };
 
 struct V4 { float x, y, z, w; };
 struct V3 { float x, y, z; };
@@ -156,7 +156,7 @@ __device__ __forceinline__ bool intersect_triangle_data(const float4 t0, const f
   V4 v0v2 = mk4(t1.z, t1.w, t2.x, 0.0f);
   V4 pvec = cross4(ray.d, v0v2);
   float det = dot4(v0v1, pvec);
-  if (PROGRAM == kBasic) {
+  if (PROGRAM == kBasic || PROGRAM == kCustom) {
     if (__builtin_fabsf(det) < 0.0000001f) return false;
   } else if (PROGRAM == kBasicLighting) {
     if ((double)__builtin_fabsf(det) < 0.0000001) return false;
@@ -570,6 +570,16 @@ __device__ inline V3 shade_basic(const SceneDev& sc, Ray ray, Stack<CFG::kDeep>&
   return out;
 }
 
+// examples/custom_kernel/resources/kernels/custom_opencl.cl:226-246 -- basic.cl without the lens code; the colour is the
+// hit's barycentrics (u, v, 1.0 - u - v), the last one computed in double
+template <class CFG>
+__device__ inline V3 shade_custom(const SceneDev& sc, const Ray& ray, Stack<CFG::kDeep>& st, Counters& c) {
+  Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
+  traverse_camera<kCustom, CFG::kDeep, CFG::kStats>(sc, ray, pl, st, c);
+  if (pl.hitType == 1) return V3{pl.u, pl.v, (float)((1.0 - (double)pl.u) - (double)pl.v)};
+  return V3{0.0f, 0.0f, 0.0f};
+}
+
 // acc.cl:219-282 / basic_lighting.cl:220-277
 template <int PROGRAM, class CFG>
 __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, float fx, float fy, uint32_t s,
@@ -715,6 +725,8 @@ __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int 
   V3 color;
   if (PROGRAM == kBasic) {
     color = shade_basic<CFG>(sc, ray, st, c);
+  } else if (PROGRAM == kCustom) {
+    color = shade_custom<CFG>(sc, ray, st, c);
   } else if (PROGRAM == kAccumulator) {
     color = shade_lighting<kAccumulator, CFG>(sc, ray, fx, fy, fp.frameCount, st, c);
   } else if (PROGRAM == kGI) {
@@ -734,7 +746,7 @@ __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int 
       }
     }
   }
-  if (PROGRAM != kBasic && fp.clampOutput) color = V3{Math<CFG::kDevLibm>::clamp01(color.x), Math<CFG::kDevLibm>::clamp01(color.y), Math<CFG::kDevLibm>::clamp01(color.z)};
+  if (PROGRAM != kBasic && PROGRAM != kCustom && fp.clampOutput) color = V3{Math<CFG::kDevLibm>::clamp01(color.x), Math<CFG::kDevLibm>::clamp01(color.y), Math<CFG::kDevLibm>::clamp01(color.z)};
   return color;
 }
 

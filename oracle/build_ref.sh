@@ -28,6 +28,7 @@ declare -A K=(
   [accumulator]=examples/accumulator/resources/kernels/accumulator.cl
   [global_illumination]=examples/global_illumination/resources/kernels/global_illumination.cl
   [global_illumination25]=resources/kernels/opencl/global_illumination.cl
+  [custom_opencl]=examples/custom_kernel/resources/kernels/custom_opencl.cl
 )
 for name in "${!K[@]}"; do
   src="$REF/${K[$name]}"

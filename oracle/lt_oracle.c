@@ -11,6 +11,8 @@
  *   examples/accumulator/resources/kernels/accumulator.cl           (program ACCUMULATOR)
  *   examples/global_illumination/resources/kernels/global_illumination.cl   (program GI)
  *   resources/kernels/opencl/global_illumination.cl                 (program GI25)
+ *   examples/custom_kernel/resources/kernels/custom_opencl.cl       (program CUSTOM: basic.cl without the lens code, shade
+ *                                                                    returns the barycentrics as colour, :232-243)
  *   examples/accumulator/resources/shaders/accumulator.frag:10-20   (running mean)
  *
  * Floating-point model ("strict OpenCL C on ROCm"):  user-level expressions are
@@ -95,7 +97,7 @@ typedef char check_prim[(sizeof(Prim) == 76) ? 1 : -1];
 typedef char check_light[(sizeof(Lights) == 260) ? 1 : -1];
 typedef char check_cam[(sizeof(Cam) == 28) ? 1 : -1];
 
-enum { LT_BASIC = 0, LT_BASIC_LIGHTING = 1, LT_ACCUMULATOR = 2, LT_GI = 3, LT_GI25 = 4 };
+enum { LT_BASIC = 0, LT_BASIC_LIGHTING = 1, LT_ACCUMULATOR = 2, LT_GI = 3, LT_GI25 = 4, LT_CUSTOM = 5 };
 enum { LT_MODE_LINEAR = 0, LT_MODE_TILE = 1 };
 
 typedef struct {
@@ -191,7 +193,7 @@ static int intersectTriangle(Ctx* c, int program, Payload* pl, Ray ray, const Pr
   f4 v0v2 = sub4(C, A);
   f4 pvec = cross4(ray.direction, v0v2);
   float det = dot4(v0v1, pvec);
-  if (program == LT_BASIC) {
+  if (program == LT_BASIC || program == LT_CUSTOM) {
     const float EPSILON = 0.0000001;
     if (fabsf(det) < EPSILON) return 0;
   } else if (program == LT_BASIC_LIGHTING) {
@@ -371,6 +373,19 @@ static f3 shade_basic(Ctx* c, Ray cameraRay) {
   return out;
 }
 
+/* custom_opencl.cl:226-246: colour = (u, v, 1.0 - u - v), the last component computed in double */
+static f3 shade_custom(Ctx* c, Ray cameraRay) {
+  f3 out = {0, 0, 0};
+  Payload pl = payload_init(FLT_MAX);
+  traverse(c, LT_CUSTOM, &pl, cameraRay, 0, 0);
+  if (pl.hitType == 1) {
+    out.x = pl.u;
+    out.y = pl.v;
+    out.z = (float)((1.0 - (double)pl.u) - (double)pl.v);
+  }
+  return out;
+}
+
 /* light sample + shadow ray shared by accumulator.cl:239-279, basic_lighting.cl:234-274
  * and the direct/extension terms of global_illumination.cl(ex):267-297,:323-349.
  * normal_w is 0 in accumulator/basic_lighting and 1 in GI.
@@ -523,6 +538,8 @@ static void pixel(Ctx* c, int program, int mode, const Cam* cam, int blockIDX, i
   f3 color;
   if (program == LT_BASIC) {
     color = shade_basic(c, ray);
+  } else if (program == LT_CUSTOM) {
+    color = shade_custom(c, ray);
   } else if (program == LT_ACCUMULATOR) {
     color = shade_lighting(c, program, ray, film.x, film.y, cam->frameCount);
   } else if (program == LT_GI) {
@@ -541,7 +558,7 @@ static void pixel(Ctx* c, int program, int mode, const Cam* cam, int blockIDX, i
     }
   }
   /* linearKernel of the lighting flavours clamps, tileKernel and basic do not */
-  if (program != LT_BASIC && mode == LT_MODE_LINEAR) {
+  if (program != LT_BASIC && program != LT_CUSTOM && mode == LT_MODE_LINEAR) {
     color.x = clamp01(color.x); color.y = clamp01(color.y); color.z = clamp01(color.z);
   }
   rgb[0] = color.x; rgb[1] = color.y; rgb[2] = color.z;

@@ -11,9 +11,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liblt_oracle.so")
 
-BASIC, BASIC_LIGHTING, ACCUMULATOR, GI, GI25 = range(5)
+BASIC, BASIC_LIGHTING, ACCUMULATOR, GI, GI25, CUSTOM = range(6)
 PROGRAMS = {"basic": BASIC, "basic_lighting": BASIC_LIGHTING, "accumulator": ACCUMULATOR,
-            "global_illumination": GI, "global_illumination25": GI25}
+            "global_illumination": GI, "global_illumination25": GI25, "custom_opencl": CUSTOM}
 MODE_LINEAR, MODE_TILE = 0, 1
 
 

@@ -19,7 +19,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REF_DIR = os.path.join(_HERE, "_ref")
 
-KERNELS = ["basic", "basic_lighting", "accumulator", "global_illumination", "global_illumination25"]
+KERNELS = ["basic", "basic_lighting", "accumulator", "global_illumination", "global_illumination25", "custom_opencl"]
 
 
 def available(kernel="basic", flavor="strict"):

@@ -32,6 +32,7 @@ def test_library_exports_every_declared_symbol():
     ("resources/kernels/global_illumination.cl", C.PROGRAM_GLOBAL_ILLUMINATION),
     ("resources/kernels/opencl/global_illumination.cl", C.PROGRAM_GLOBAL_ILLUMINATION_25),
     ("basic", C.PROGRAM_BASIC),
+    ("examples/custom_kernel/resources/kernels/custom_opencl.cl", C.PROGRAM_CUSTOM_OPENCL),
 ])
 def test_program_from_path(path, prog):
     assert C.program_from_path(path) == prog
@@ -39,7 +40,7 @@ def test_program_from_path(path, prog):
 
 def test_unknown_program_is_an_error():
     with pytest.raises(C.LensTraceError):
-        C.program_from_path("examples/custom_kernel/resources/kernels/custom_opencl.cl")
+        C.program_from_path("resources/kernels/opencl/some_user_kernel.cl")
 
 
 def test_output_floats_and_desc_validation():

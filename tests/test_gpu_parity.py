@@ -25,6 +25,7 @@ KERNEL_PATHS = {
     "accumulator": "examples/accumulator/resources/kernels/accumulator.cl",
     "global_illumination": "examples/global_illumination/resources/kernels/global_illumination.cl",
     "global_illumination25": "resources/kernels/opencl/global_illumination.cl",
+    "custom_opencl": "examples/custom_kernel/resources/kernels/custom_opencl.cl",
 }
 
 
@@ -169,7 +170,7 @@ def test_errors(renderer):
     s = load("cornell_box_O0")
     out = np.zeros((10, 10, 3), dtype=np.float32)
     with pytest.raises(C.LensTraceError):
-        renderer.render(RenderPropertiesHIP("examples/custom_kernel/resources/kernels/custom_opencl.cl", (10, 10, 3), out, s, pCamera=CAM))
+        renderer.render(RenderPropertiesHIP("resources/kernels/opencl/some_user_kernel.cl", (10, 10, 3), out, s, pCamera=CAM))
     with pytest.raises(C.LensTraceError):     # buffer too small
         renderer.render(RenderPropertiesHIP(KERNEL_PATHS["basic"], (20, 20, 3), out, s, pCamera=CAM))
     bad = sc.Scene(s.nodes.copy(), s.prims.copy(), s.materials.copy(), s.lights.copy())

@@ -27,6 +27,7 @@ PATHS = {
     "accumulator": "examples/accumulator/resources/kernels/accumulator.cl",
     "global_illumination": "examples/global_illumination/resources/kernels/global_illumination.cl",
     "global_illumination25": "resources/kernels/opencl/global_illumination.cl",
+    "custom_opencl": "examples/custom_kernel/resources/kernels/custom_opencl.cl",
 }
 
 CASES = [  # scene, kernel, mode, W, H, frame
@@ -41,6 +42,8 @@ CASES = [  # scene, kernel, mode, W, H, frame
     ("cornell_box_O0", "global_illumination", 0, 128, 128, 0),
     ("cornell_box_O0", "global_illumination", 0, 256, 256, 3),
     ("cornell_box_O0", "global_illumination25", 0, 64, 64, 2),
+    ("cornell_box_lens_O0", "custom_opencl", 0, 128, 128, 0),
+    ("cornell_box_O0", "custom_opencl", 1, 96, 64, 0),
     ("cornell_box_O0", "accumulator", 0, 96, 64, 3, 0.02),     # yaw != 0: cos/sin(yaw) per work-item on the device
     ("cornell_box_O0", "global_illumination", 0, 96, 64, 1, -0.015),
 ]
