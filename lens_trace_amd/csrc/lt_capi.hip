@@ -24,16 +24,11 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
   return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
 }
 
+// One 8x8 pixel square (logical index b, already XCD-ordered) by one wavefront.
 template <int PROGRAM, class CFG>
-__global__ __launch_bounds__(kBlock) void lt_render_kernel(SceneDev sc, FrameParams fp, float* __restrict__ out,
-                                                          unsigned long long* __restrict__ stats) {
-  extern __shared__ int lds_stack[];   // [min(height + 1, kLdsStack)][kBlock], sized by the launch
+__device__ __forceinline__ void render_square(const SceneDev& sc, const FrameParams& fp, float* __restrict__ out, uint32_t b,
+                                              Stack<CFG::kDeep>& st, Counters& c) {
   constexpr bool STATS = CFG::kStats;
-  Stack<CFG::kDeep> st;
-  st.lds = lds_stack + threadIdx.x;
-  Counters c{};
-
-  const uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
   const uint32_t k = b / fp.blocksPerTile, sb = b % fp.blocksPerTile;
   const uint32_t sbx = sb % fp.blocksPerTileX, sby = sb / fp.blocksPerTileX;
   const uint32_t tile = fp.tileFirst + k * fp.tileStride;
@@ -44,10 +39,11 @@ __global__ __launch_bounds__(kBlock) void lt_render_kernel(SceneDev sc, FramePar
   const uint32_t x = tx * fp.tileW + lx, y = ty * fp.tileH + ly;
   const bool valid = k < fp.tilesInCall && lx < fp.tileW && ly < fp.tileH && x < fp.width && y < fp.height;
   if (valid) {
-    const V3 color = shade_pixel<PROGRAM, CFG>(sc, fp, (int)x, (int)y, st, c);
+    Counters pc{};   // this pixel's own counters (diagnostic output), folded into the lane's totals below
+    const V3 color = shade_pixel<PROGRAM, CFG>(sc, fp, (int)x, (int)y, st, STATS ? pc : c);
     float* o = out + (((size_t)k * fp.tileH + ly) * fp.tileW + lx) * fp.depth;
     if (STATS && fp.pixelCounters) {
-      o[0] = (float)c.rays; o[1] = (float)c.shadow; o[2] = (float)c.nodes; o[3] = (float)c.tris;
+      o[0] = (float)pc.rays; o[1] = (float)pc.shadow; o[2] = (float)pc.nodes; o[3] = (float)pc.tris;
     } else if (fp.accumulateN <= 0) {   // overwrite, or first frame of a running mean (`if (frameCount > 0)` guard)
       o[0] = color.x; o[1] = color.y; o[2] = color.z;
     } else {                     // accumulator.frag:12-18: (c + acc*n) / (n+1)
@@ -56,6 +52,57 @@ __global__ __launch_bounds__(kBlock) void lt_render_kernel(SceneDev sc, FramePar
       o[1] = (color.y + (o[1] * n)) / n1;
       o[2] = (color.z + (o[2] * n)) / n1;
     }
+    if (STATS) {
+      c.rays += pc.rays; c.shadow += pc.shadow; c.nodes += pc.nodes; c.tris += pc.tris;
+#ifdef LT_DEBUG_WAVE_COUNTERS
+      c.wInner += pc.wInner; c.wTri += pc.wTri; c.wOuter += pc.wOuter;
+#endif
+    }
+  }
+}
+
+// Registers: the traversal is latency-bound and wants every wave slot (8 per SIMD = 64 VGPRs); the single-bounce programs fit
+// that with a few spilled values in their shading code, the 16-bounce / 25-sample programs do not (85-140 spills) and are
+// left to the allocator (4 waves per SIMD).
+constexpr int waves_per_simd(int program) { return (program == kBasic || program == kAccumulator || program == kCustom) ? 8 : 1; }
+
+template <int PROGRAM, class CFG>
+__global__ __launch_bounds__(kBlock, waves_per_simd(PROGRAM)) void lt_render_kernel(SceneDev sc, FrameParams fp, float* __restrict__ out,
+                                                          unsigned long long* __restrict__ stats, uint32_t* __restrict__ queues) {
+  extern __shared__ int lds_stack[];   // [BVH height (<= kLdsStack)][kBlock], sized by the launch
+  constexpr bool STATS = CFG::kStats;
+  Stack<CFG::kDeep> st;
+  st.lds = lds_stack + threadIdx.x;
+  Counters c{};
+
+  // Two ways to hand out the 8x8 squares, one loop (a single inlined copy of the renderer):
+  //  * one square per workgroup, the hardware dispatcher doing the scheduling (workgroup ids remapped per XCD);
+  //  * persistent wavefronts: a grid just large enough to fill the chip, every wave pulling squares from the queue of the
+  //    XCD it runs on (its contiguous share of the logical square list, so each XCD's L2 keeps serving one image region)
+  //    and, when that is drained, from the other XCDs' queues.  Every wave reaches the exit: each queue hands out at most
+  //    its share, and the loop ends after one empty sweep over all eight.
+  const uint32_t n = fp.totalSquares, q = n / 8u, r = n % 8u;
+  const uint32_t home = fp.persistent ? (__builtin_amdgcn_s_getreg((3u << 11) | 20u) & 7u) : 0u;   // HW_REG_XCC_ID
+  uint32_t sweep = 0;
+  bool done = false;
+  while (!done) {
+    uint32_t b;
+    if (!fp.persistent) {
+      b = xcd_remap(blockIdx.x, gridDim.x);
+      done = true;
+    } else {
+      const uint32_t xcd = (home + sweep) & 7u;
+      const uint32_t share = q + (xcd < r ? 1u : 0u), start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+      uint32_t t = 0;
+      if (threadIdx.x == 0) t = atomicAdd(&queues[xcd], 1u);
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      if (t >= share) {
+        done = ++sweep >= 8u;
+        continue;
+      }
+      b = start + t;
+    }
+    render_square<PROGRAM, CFG>(sc, fp, out, b, st, c);
   }
   if (STATS) {
     atomicAdd(&stats[0], (unsigned long long)c.rays);
@@ -108,6 +155,9 @@ struct lt_hip_context {
   float* d_out = nullptr;            // staging output for lt_hip_render
   uint64_t d_out_bytes = 0;
   unsigned long long* d_stats = nullptr;
+  uint32_t* d_queues = nullptr;      // persistent mode: 8 per-XCD work counters per launch of a call
+  uint32_t queue_frames = 0;
+  int cu_count = 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   bool pending = false, pending_stats = false;
@@ -148,6 +198,7 @@ extern "C" int lt_hip_create(int device_index, lt_hip_context** out_ctx) {
     return fail(nullptr, LT_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
   lt_hip_context* ctx = new lt_hip_context();
   ctx->device = device_index;
+  ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   auto bail = [&](const char* what, hipError_t er) {
     std::string m = std::string(what) + ": " + hipGetErrorString(er);
     delete ctx;
@@ -177,6 +228,7 @@ extern "C" int lt_hip_destroy(lt_hip_context* ctx) {
   free_scene(ctx);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+  if (ctx->d_queues) (void)hipFree(ctx->d_queues);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -326,8 +378,8 @@ struct LaunchConfig { bool deep, stats, devlibm; };
 
 template <int PROGRAM>
 static void launch_program(const LaunchConfig& k, dim3 grid, uint32_t lds, hipStream_t s, const SceneDev& sc, const FrameParams& fp,
-                           float* out, unsigned long long* st) {
-#define LT_LAUNCH(D, S, M) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, Config<D, S, M>>), grid, dim3(kBlock), lds, s, sc, fp, out, st)
+                           float* out, unsigned long long* st, uint32_t* queues) {
+#define LT_LAUNCH(D, S, M) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, Config<D, S, M>>), grid, dim3(kBlock), lds, s, sc, fp, out, st, queues)
   if (k.devlibm) {          // verification flavour: no counters
     if (k.deep) LT_LAUNCH(true, false, true); else LT_LAUNCH(false, false, true);
   } else if (k.deep) {
@@ -391,23 +443,40 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   if (nblocks > 0x7fffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many workgroups");
 
   if (stats) LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), s));
+  // persistent wavefronts by default; LT_PERSISTENT=0 selects one-square-per-workgroup dispatch (A/B measurements)
+  const char* pe = getenv("LT_PERSISTENT");
+  const bool persistent = !pe || atoi(pe) != 0;
+  if (persistent) {
+    if (ctx->queue_frames < frames) {
+      if (ctx->d_queues) LT_HIP_CHECK(ctx, hipFree(ctx->d_queues));
+      ctx->d_queues = nullptr;
+      ctx->queue_frames = 0;
+      LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_queues, (size_t)frames * 8 * sizeof(uint32_t)));
+      ctx->queue_frames = frames;
+    }
+    LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queues, 0, (size_t)frames * 8 * sizeof(uint32_t), s));
+  }
+  fp.totalSquares = (uint32_t)nblocks;
+  fp.persistent = persistent;
   LT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, s));
   uint32_t launches = 0;
   if (nblocks > 0) {
     for (uint32_t f = 0; f < frames; f++) {
       fp.frameCount = d->frame_count ? d->frame_first + f : camFrame;
       fp.accumulateN = (d->frame_count && d->accumulate) ? (int32_t)(d->accumulate_base + f) : -1;
-      const dim3 grid((uint32_t)nblocks);
+      const uint32_t resident = (uint32_t)ctx->cu_count * 32u;   // every wave slot of the chip, once
+      const dim3 grid(persistent ? (uint32_t)std::min<uint64_t>(nblocks, resident) : (uint32_t)nblocks);
+      uint32_t* queues = persistent ? ctx->d_queues + (size_t)f * 8 : nullptr;
       // LDS stack rows: with the top entry in a register, the rows below it number at most (interior levels - 1)
       uint32_t lds = (uint32_t)std::max(1, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
       switch (d->program) {
-        case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
-        case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
-        case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
-        case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
-        case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
-        default: launch_program<kCustom>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats); break;
+        case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
+        case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
+        case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
+        case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
+        case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
+        default: launch_program<kCustom>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
       }
       LT_HIP_CHECK(ctx, hipGetLastError());
       launches++;

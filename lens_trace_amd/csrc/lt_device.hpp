@@ -696,7 +696,9 @@ struct FrameParams {
   int32_t accumulateN;      // < 0: overwrite; >= 0: running mean with n = accumulateN (accumulator.frag:10-20)
   // tile sharding (lenstrace_hip.h): tiles tile_first + k*tile_stride, k < tilesInCall
   uint32_t tileW, tileH, tilesX, tileFirst, tileStride, tilesInCall;
-  uint32_t blocksPerTileX, blocksPerTile;   // 16x16-pixel workgroup tiles per image tile
+  uint32_t blocksPerTileX, blocksPerTile;   // 8x8-pixel wavefront squares per image tile
+  uint32_t totalSquares;                    // tilesInCall * blocksPerTile
+  uint32_t persistent;                      // != 0: waves pull squares from per-XCD queues instead of one square per workgroup
 };
 
 // Camera ray of pixel (x,y): acc.cl:304-312.
