@@ -62,9 +62,12 @@ __device__ __forceinline__ void render_square(const SceneDev& sc, const FramePar
 }
 
 // Registers: the traversal is latency-bound and wants every wave slot (8 per SIMD = 64 VGPRs); the single-bounce programs fit
-// that with a few spilled values in their shading code, the 16-bounce / 25-sample programs do not (85-140 spills) and are
-// left to the allocator (4 waves per SIMD).
-constexpr int waves_per_simd(int program) { return (program == kBasic || program == kAccumulator || program == kCustom) ? 8 : 1; }
+// that with a few spilled values in their shading code; the 16-bounce / 25-sample programs would spill 85-140 values at 8
+// and run best at 5 waves per SIMD (Cornell GI 1080p, 16 bounces: 3.7 / 3.4 / 3.2 / 3.4 / 4.4 ms at 3 / 4 / 5 / 6 / 8).
+#ifndef LT_GI_WAVES
+#define LT_GI_WAVES 5
+#endif
+constexpr int waves_per_simd(int program) { return (program == kBasic || program == kAccumulator || program == kCustom) ? 8 : LT_GI_WAVES; }
 
 template <int PROGRAM, class CFG>
 __global__ __launch_bounds__(kBlock, waves_per_simd(PROGRAM)) void lt_render_kernel(SceneDev sc, FrameParams fp, float* __restrict__ out,
