@@ -139,6 +139,19 @@ const char* lt_hip_last_error(const lt_hip_context* ctx);
  * and does not contain "examples/", as in the reference tree. */
 int lt_hip_program_from_path(const char* kernel_file_path, int* out_program);
 
+/* program ids >= LT_PROGRAM_USER_BASE are user programs of one context, handed out by lt_hip_resolve_program */
+#define LT_PROGRAM_USER_BASE 1000
+
+/* The reference's "kernelFilePath names a source file that is compiled at first use and cached by path"
+ * (renderer_opencl.cpp:35-54, :67-70): a path whose basename is a built-in program resolves like
+ * lt_hip_program_from_path; any other path ending in ".hip" is read as a USER PROGRAM -- a HIP source file defining
+ *     template <class CFG> __device__ lt::V3 lt::user_shade(const SceneDev&, const Ray& cameraRay, float filmX, float filmY,
+ *                                                            uint32_t frameCount, Stack<CFG::kDeep>&, Counters&);
+ * (the shade step; traversal, camera rays, framebuffer and scheduling are the built-in ones, lens_trace_amd/csrc/lt_kernel.hpp)
+ * -- compiled for gfx950 with hipRTC (-O3 -ffp-contract=off), cached by path for the life of the context.  Compile errors
+ * are reported through lt_hip_last_error (LT_ERR_UNKNOWN_PROGRAM). */
+int lt_hip_resolve_program(lt_hip_context* ctx, const char* kernel_file_path, int* out_program);
+
 /* Uploads (host pointers) and validates the four scene buffers; keeps them resident until the next
  * set_scene / destroy.  Also builds the traversal-side triangle array (48-byte stride: A, B-A, C-A).  The BVH is
  * traversed in the uploaded LinearBVHNode layout itself. */

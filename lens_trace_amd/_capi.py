@@ -20,6 +20,7 @@ RENDER_FLAG_DEVICE_LIBM = 4
 
 # every symbol include/lenstrace_hip.h declares
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",
+           "lt_hip_resolve_program",
            "lt_hip_set_scene", "lt_hip_output_floats", "lt_hip_render", "lt_hip_render_device", "lt_hip_untile",
            "lt_hip_synchronize", "lt_hip_get_stats"]
 
@@ -78,6 +79,7 @@ def load():
     L.lt_hip_last_error.argtypes = [vp]
     L.lt_hip_last_error.restype = ctypes.c_char_p
     L.lt_hip_program_from_path.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32)]
+    L.lt_hip_resolve_program.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i32)]
     L.lt_hip_set_scene.argtypes = [vp, vp, u64, vp, u64, vp, u64, vp, u64]
     L.lt_hip_output_floats.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(u64)]
     L.lt_hip_render.argtypes = [vp, ctypes.POINTER(RenderDesc), vp, u64]

@@ -1,124 +1,21 @@
 // lt_capi.hip -- liblenstrace-hip.so: the C ABI of include/lenstrace_hip.h over hand-written gfx950 kernels.
 // Host side of what the reference does in RendererOpenCL::render() (src/opencl/renderer_opencl.cpp:56-153).
-#include "lt_device.hpp"
+#include "lt_kernel.hpp"
 
 #include "../../include/lenstrace_hip.h"
+
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
 #include <string>
 #include <vector>
-
-using namespace lt;
-
-// ---------------------------------------------------------------------------------- kernels
-// One lane per pixel; a workgroup is ONE wavefront covering an 8x8 pixel square (no intra-workgroup tail: the
-// LDS stack and the wave slot are released as soon as that wave's slowest ray ends).  Workgroup ids are
-// remapped so that the blocks one XCD receives (ids congruent mod 8) cover one contiguous part of the
-// image: each XCD's private L2 then holds the BVH subtrees of its own image region.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
-  const uint32_t q = n / 8u, r = n % 8u, xcd = b % 8u;
-  return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
-}
-
-// One 8x8 pixel square (logical index b, already XCD-ordered) by one wavefront.
-template <int PROGRAM, class CFG>
-__device__ __forceinline__ void render_square(const SceneDev& sc, const FrameParams& fp, float* __restrict__ out, uint32_t b,
-                                              Stack<CFG::kDeep>& st, Counters& c) {
-  constexpr bool STATS = CFG::kStats;
-  const uint32_t k = b / fp.blocksPerTile, sb = b % fp.blocksPerTile;
-  const uint32_t sbx = sb % fp.blocksPerTileX, sby = sb / fp.blocksPerTileX;
-  const uint32_t tile = fp.tileFirst + k * fp.tileStride;
-  const uint32_t tx = tile % fp.tilesX, ty = tile / fp.tilesX;
-  const uint32_t lane = threadIdx.x;
-  const uint32_t lx = sbx * 8u + (lane & 7u);
-  const uint32_t ly = sby * 8u + (lane >> 3);
-  const uint32_t x = tx * fp.tileW + lx, y = ty * fp.tileH + ly;
-  const bool valid = k < fp.tilesInCall && lx < fp.tileW && ly < fp.tileH && x < fp.width && y < fp.height;
-  if (valid) {
-    Counters pc{};   // this pixel's own counters (diagnostic output), folded into the lane's totals below
-    const V3 color = shade_pixel<PROGRAM, CFG>(sc, fp, (int)x, (int)y, st, STATS ? pc : c);
-    float* o = out + (((size_t)k * fp.tileH + ly) * fp.tileW + lx) * fp.depth;
-    if (STATS && fp.pixelCounters) {
-      o[0] = (float)pc.rays; o[1] = (float)pc.shadow; o[2] = (float)pc.nodes; o[3] = (float)pc.tris;
-    } else if (fp.accumulateN <= 0) {   // overwrite, or first frame of a running mean (`if (frameCount > 0)` guard)
-      o[0] = color.x; o[1] = color.y; o[2] = color.z;
-    } else {                     // accumulator.frag:12-18: (c + acc*n) / (n+1)
-      const float n = (float)fp.accumulateN, n1 = (float)(fp.accumulateN + 1);
-      o[0] = (color.x + (o[0] * n)) / n1;
-      o[1] = (color.y + (o[1] * n)) / n1;
-      o[2] = (color.z + (o[2] * n)) / n1;
-    }
-    if (STATS) {
-      c.rays += pc.rays; c.shadow += pc.shadow; c.nodes += pc.nodes; c.tris += pc.tris;
-#ifdef LT_DEBUG_WAVE_COUNTERS
-      c.wInner += pc.wInner; c.wTri += pc.wTri; c.wOuter += pc.wOuter;
-#endif
-    }
-  }
-}
-
-// Registers: the traversal is latency-bound and wants every wave slot (8 per SIMD = 64 VGPRs); the single-bounce programs fit
-// that with a few spilled values in their shading code; the 16-bounce / 25-sample programs would spill 85-140 values at 8
-// and run best at 5 waves per SIMD (Cornell GI 1080p, 16 bounces: 3.7 / 3.4 / 3.2 / 3.4 / 4.4 ms at 3 / 4 / 5 / 6 / 8).
-#ifndef LT_GI_WAVES
-#define LT_GI_WAVES 5
-#endif
-constexpr int waves_per_simd(int program) { return (program == kBasic || program == kAccumulator || program == kCustom) ? 8 : LT_GI_WAVES; }
-
-template <int PROGRAM, class CFG>
-__global__ __launch_bounds__(kBlock, waves_per_simd(PROGRAM)) void lt_render_kernel(SceneDev sc, FrameParams fp, float* __restrict__ out,
-                                                          unsigned long long* __restrict__ stats, uint32_t* __restrict__ queues) {
-  extern __shared__ int lds_stack[];   // [BVH height (<= kLdsStack)][kBlock], sized by the launch
-  constexpr bool STATS = CFG::kStats;
-  Stack<CFG::kDeep> st;
-  st.lds = lds_stack + threadIdx.x;
-  Counters c{};
-
-  // Two ways to hand out the 8x8 squares, one loop (a single inlined copy of the renderer):
-  //  * one square per workgroup, the hardware dispatcher doing the scheduling (workgroup ids remapped per XCD);
-  //  * persistent wavefronts: a grid just large enough to fill the chip, every wave pulling squares from the queue of the
-  //    XCD it runs on (its contiguous share of the logical square list, so each XCD's L2 keeps serving one image region)
-  //    and, when that is drained, from the other XCDs' queues.  Every wave reaches the exit: each queue hands out at most
-  //    its share, and the loop ends after one empty sweep over all eight.
-  const uint32_t n = fp.totalSquares, q = n / 8u, r = n % 8u;
-  const uint32_t home = fp.persistent ? (__builtin_amdgcn_s_getreg((3u << 11) | 20u) & 7u) : 0u;   // HW_REG_XCC_ID
-  uint32_t sweep = 0;
-  bool done = false;
-  while (!done) {
-    uint32_t b;
-    if (!fp.persistent) {
-      b = xcd_remap(blockIdx.x, gridDim.x);
-      done = true;
-    } else {
-      const uint32_t xcd = (home + sweep) & 7u;
-      const uint32_t share = q + (xcd < r ? 1u : 0u), start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-      uint32_t t = 0;
-      if (threadIdx.x == 0) t = atomicAdd(&queues[xcd], 1u);
-      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-      if (t >= share) {
-        done = ++sweep >= 8u;
-        continue;
-      }
-      b = start + t;
-    }
-    render_square<PROGRAM, CFG>(sc, fp, out, b, st, c);
-  }
-  if (STATS) {
-    atomicAdd(&stats[0], (unsigned long long)c.rays);
-    atomicAdd(&stats[1], (unsigned long long)c.shadow);
-    atomicAdd(&stats[2], (unsigned long long)c.nodes);
-    atomicAdd(&stats[3], (unsigned long long)c.tris);
-#ifdef LT_DEBUG_WAVE_COUNTERS
-    atomicAdd(&stats[4], (unsigned long long)c.wInner);
-    atomicAdd(&stats[5], (unsigned long long)c.wTri);
-    atomicAdd(&stats[6], (unsigned long long)c.wOuter);
-#endif
-  }
-}
 
 // Triangle re-tiling at upload: 76-byte Primitive -> 48-byte (A, B-A, C-A, 0 0 0).
 __global__ void lt_retile_kernel(const float* __restrict__ prims, float4* __restrict__ tris, uint32_t n) {
@@ -165,6 +62,10 @@ struct lt_hip_context {
   hipStream_t last_stream = nullptr;
   bool pending = false, pending_stats = false;
   lt_hip_stats last{};
+  // user programs (hipRTC), cached by path like the reference's programMap
+  struct UserProgram { hipModule_t module; hipFunction_t lds, deep; };
+  std::vector<UserProgram> user_programs;
+  std::map<std::string, int> user_program_ids;
 };
 
 static thread_local std::string g_create_error;
@@ -232,6 +133,7 @@ extern "C" int lt_hip_destroy(lt_hip_context* ctx) {
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
   if (ctx->d_queues) (void)hipFree(ctx->d_queues);
+  for (auto& up : ctx->user_programs) (void)hipModuleUnload(up.module);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -256,6 +158,103 @@ extern "C" int lt_hip_program_from_path(const char* path, int* out_program) {
     *out_program = shipped25 ? LT_PROGRAM_GLOBAL_ILLUMINATION_25 : LT_PROGRAM_GLOBAL_ILLUMINATION;
   } else return LT_ERR_UNKNOWN_PROGRAM;
   return LT_OK;
+}
+
+// ---------------------------------------------------------------------------------- user programs (hipRTC)
+// hipRTC is loaded on first use (dlopen), so the library has no link-time dependency on it.
+namespace {
+struct Hiprtc {
+  void* lib = nullptr;
+  int (*createProgram)(void**, const char*, const char*, int, const char**, const char**) = nullptr;
+  int (*compileProgram)(void*, int, const char**) = nullptr;
+  int (*getProgramLogSize)(void*, size_t*) = nullptr;
+  int (*getProgramLog)(void*, char*) = nullptr;
+  int (*getCodeSize)(void*, size_t*) = nullptr;
+  int (*getCode)(void*, char*) = nullptr;
+  int (*destroyProgram)(void**) = nullptr;
+  bool load(std::string& err) {
+    if (lib) return true;
+    for (const char* name : {"libhiprtc.so.7", "libhiprtc.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) { err = "hipRTC library not found (libhiprtc.so)"; return false; }
+#define LT_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(lib, sym)); if (!field) { err = std::string("hipRTC symbol missing: ") + sym; return false; }
+    LT_SYM(createProgram, "hiprtcCreateProgram") LT_SYM(compileProgram, "hiprtcCompileProgram")
+    LT_SYM(getProgramLogSize, "hiprtcGetProgramLogSize") LT_SYM(getProgramLog, "hiprtcGetProgramLog")
+    LT_SYM(getCodeSize, "hiprtcGetCodeSize") LT_SYM(getCode, "hiprtcGetCode") LT_SYM(destroyProgram, "hiprtcDestroyProgram")
+#undef LT_SYM
+    return true;
+  }
+};
+Hiprtc g_hiprtc;
+
+// directory of the device headers: <this library>/../csrc, or $LT_CSRC_DIR
+std::string csrc_dir() {
+  if (const char* e = getenv("LT_CSRC_DIR")) return e;
+  Dl_info info;
+  if (dladdr((const void*)&lt_hip_abi_version, &info) && info.dli_fname) {
+    std::string p(info.dli_fname);
+    const size_t slash = p.find_last_of('/');
+    return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/../csrc";
+  }
+  return "lens_trace_amd/csrc";
+}
+}  // namespace
+
+static int compile_user_program(lt_hip_context* ctx, const std::string& path, int* out_program) {
+  std::ifstream in(path);
+  if (!in) return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "cannot read user program " + path);
+  std::stringstream user;
+  user << in.rdbuf();
+  std::string err;
+  if (!g_hiprtc.load(err)) return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, err);
+  const std::string src = "#define LT_USER_PROGRAM 1\n#include \"lt_kernel.hpp\"\n#line 1 \"" + path + "\"\n" + user.str() +
+      "\nextern \"C\" __global__ __launch_bounds__(64) void lt_user_kernel_lds(SceneDev sc, FrameParams fp, float* out, unsigned long long* stats, uint32_t* queues) {\n"
+      "  render_kernel_body<kUser, Config<false, false, false>>(sc, fp, out, stats, queues);\n}\n"
+      "extern \"C\" __global__ __launch_bounds__(64) void lt_user_kernel_deep(SceneDev sc, FrameParams fp, float* out, unsigned long long* stats, uint32_t* queues) {\n"
+      "  render_kernel_body<kUser, Config<true, false, false>>(sc, fp, out, stats, queues);\n}\n";
+  void* prog = nullptr;
+  if (g_hiprtc.createProgram(&prog, src.c_str(), "lt_user_program.hip", 0, nullptr, nullptr) != 0)
+    return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "hiprtcCreateProgram failed");
+  const std::string inc = "-I" + csrc_dir();
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str()};
+  const int rc = g_hiprtc.compileProgram(prog, 5, opts);
+  size_t n = 0;
+  std::string log;
+  if (g_hiprtc.getProgramLogSize(prog, &n) == 0 && n > 1) {
+    log.resize(n);
+    g_hiprtc.getProgramLog(prog, &log[0]);
+  }
+  if (rc != 0) {
+    g_hiprtc.destroyProgram(&prog);
+    return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "user program " + path + " failed to compile:\n" + log);
+  }
+  std::vector<char> code;
+  if (g_hiprtc.getCodeSize(prog, &n) != 0 || n == 0) { g_hiprtc.destroyProgram(&prog); return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "hiprtcGetCodeSize failed"); }
+  code.resize(n);
+  g_hiprtc.getCode(prog, code.data());
+  g_hiprtc.destroyProgram(&prog);
+  lt_hip_context::UserProgram up{};
+  LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  LT_HIP_CHECK(ctx, hipModuleLoadData(&up.module, code.data()));
+  LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.lds, up.module, "lt_user_kernel_lds"));
+  LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.deep, up.module, "lt_user_kernel_deep"));
+  ctx->user_programs.push_back(up);
+  *out_program = LT_PROGRAM_USER_BASE + (int)ctx->user_programs.size() - 1;
+  ctx->user_program_ids[path] = *out_program;
+  return LT_OK;
+}
+
+extern "C" int lt_hip_resolve_program(lt_hip_context* ctx, const char* path, int* out_program) {
+  if (!ctx || !path || !out_program) return LT_ERR_INVALID_ARGUMENT;
+  if (lt_hip_program_from_path(path, out_program) == LT_OK) return LT_OK;
+  const std::string p(path);
+  if (p.size() < 5 || p.compare(p.size() - 4, 4, ".hip") != 0)
+    return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "no built-in program for " + p + " (user programs are .hip files)");
+  auto it = ctx->user_program_ids.find(p);
+  if (it != ctx->user_program_ids.end()) { *out_program = it->second; return LT_OK; }
+  return compile_user_program(ctx, p, out_program);
 }
 
 // Host-side validation: nothing with an out-of-range index or a cycle may reach a kernel.
@@ -400,7 +399,12 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   std::string msg;
   int rc = plan_tiles(d, p, msg);
   if (rc) return fail(ctx, rc, msg);
-  if (d->program < LT_PROGRAM_BASIC || d->program > LT_PROGRAM_CUSTOM_OPENCL) return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "unknown program");
+  const bool userProgram = d->program >= LT_PROGRAM_USER_BASE;
+  if (userProgram ? (size_t)(d->program - LT_PROGRAM_USER_BASE) >= ctx->user_programs.size()
+                  : (d->program < LT_PROGRAM_BASIC || d->program > LT_PROGRAM_CUSTOM_OPENCL))
+    return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "unknown program");
+  if (userProgram && (d->flags & (LT_RENDER_FLAG_STATS | LT_RENDER_FLAG_PIXEL_COUNTERS | LT_RENDER_FLAG_DEVICE_LIBM)))
+    return fail(ctx, LT_ERR_INVALID_ARGUMENT, "user programs are compiled without the counting / device-libm variants");
   if (d->kernel_mode != LT_KERNEL_MODE_LINEAR && d->kernel_mode != LT_KERNEL_MODE_TILE) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "unknown kernel mode");
   if (!out_device) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "output pointer is NULL");
   if (out_bytes < p.floats * sizeof(float)) return fail(ctx, LT_ERR_BUFFER_TOO_SMALL, "output buffer smaller than the image/tile stack");
@@ -473,6 +477,15 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       // LDS stack rows: with the top entry in a register, the rows below it number at most (interior levels - 1)
       uint32_t lds = (uint32_t)std::max(1, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
+      if (userProgram) {
+        const lt_hip_context::UserProgram& up = ctx->user_programs[d->program - LT_PROGRAM_USER_BASE];
+        unsigned long long* statsPtr = ctx->d_stats;
+        float* outPtr = out_device;
+        void* args[] = {(void*)&sc, (void*)&fp, (void*)&outPtr, (void*)&statsPtr, (void*)&queues};
+        LT_HIP_CHECK(ctx, hipModuleLaunchKernel(deep ? up.deep : up.lds, grid.x, 1, 1, kBlock, 1, 1, lds, s, args, nullptr));
+        launches++;
+        continue;
+      }
       switch (d->program) {
         case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
         case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;

@@ -9,8 +9,16 @@
 // defines them on gfx950 (dot = fma chain, cross = fma(a,b,-(c*d))); see DESIGN.md "Floating-point
 // model".  hipcc's defaults give IEEE f32 divide / sqrt and keep f32 denormals.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else   // hipRTC has no system headers; its own fixed-width types live in __hip_internal
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned long long uint64_t;
+#endif
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -23,7 +31,7 @@ constexpr int kLdsStack = 32;      // most traversal-stack entries per lane held
 constexpr int kMaxStack = 64;      // the reference's nodesToVisit[64] (acc.cl:137)
 constexpr float kFltMax = 3.402823466e+38f;
 
-enum Program { kBasic = 0, kBasicLighting = 1, kAccumulator = 2, kGI = 3, kGI25 = 4, kCustom = 5 };
+enum Program { kBasic = 0, kBasicLighting = 1, kAccumulator = 2, kGI = 3, kGI25 = 4, kCustom = 5, kUser = 1000 };
 
 struct V4 { float x, y, z, w; };
 struct V3 { float x, y, z; };
@@ -355,8 +363,8 @@ template <int PROGRAM, bool STATS>
 __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool nxU, bool nyU, bool nzU,
                                        Hit& pl, int* ldsWave, Counters& c) {
   using u64 = unsigned long long;
-  const ConstF4 nodes = (ConstF4)(uintptr_t)sc.nodes;
-  const ConstF4 tris = (ConstF4)(uintptr_t)sc.tris;
+  const ConstF4 nodes = (ConstF4)(unsigned long long)sc.nodes;
+  const ConstF4 tris = (ConstF4)(unsigned long long)sc.tris;
   const int lane = (int)__lane_id();
   u64 mask = __ballot(1);
   const int leader = __ffsll((long long)mask) - 1;
@@ -718,6 +726,16 @@ __device__ __forceinline__ Ray camera_ray(const FrameParams& fp, int x, int y, f
   return ray;
 }
 
+#ifdef LT_USER_PROGRAM
+// The shade step of a run-time compiled user program (the counterpart of `shade` in the reference's kernel files, e.g.
+// custom_opencl.cl:226-246): defined by the user's source file, called once per pixel with the camera ray of
+// linearKernel (acc.cl:304-312), the film position and the camera's frameCount.  Everything in this header is at its
+// disposal: traverse_camera<>, traverse<>, intersect helpers, random_, Math<>, the scene buffers.
+template <class CFG>
+__device__ V3 user_shade(const SceneDev& sc, const Ray& cameraRay, float filmX, float filmY, uint32_t frameCount,
+                         Stack<CFG::kDeep>& st, Counters& c);
+#endif
+
 // The body of linearKernel / tileKernel for one pixel, all five programs
 // (acc.cl:314-318, basic.cl:338-342, basic_lighting.cl:309-321, resources gi :408-420).
 template <int PROGRAM, class CFG>
@@ -729,6 +747,10 @@ __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int 
     color = shade_basic<CFG>(sc, ray, st, c);
   } else if (PROGRAM == kCustom) {
     color = shade_custom<CFG>(sc, ray, st, c);
+#ifdef LT_USER_PROGRAM
+  } else if (PROGRAM == kUser) {
+    color = user_shade<CFG>(sc, ray, fx, fy, fp.frameCount, st, c);
+#endif
   } else if (PROGRAM == kAccumulator) {
     color = shade_lighting<kAccumulator, CFG>(sc, ray, fx, fy, fp.frameCount, st, c);
   } else if (PROGRAM == kGI) {
@@ -748,7 +770,7 @@ __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int 
       }
     }
   }
-  if (PROGRAM != kBasic && PROGRAM != kCustom && fp.clampOutput) color = V3{Math<CFG::kDevLibm>::clamp01(color.x), Math<CFG::kDevLibm>::clamp01(color.y), Math<CFG::kDevLibm>::clamp01(color.z)};
+  if (PROGRAM != kBasic && PROGRAM != kCustom && PROGRAM != kUser && fp.clampOutput) color = V3{Math<CFG::kDevLibm>::clamp01(color.x), Math<CFG::kDevLibm>::clamp01(color.y), Math<CFG::kDevLibm>::clamp01(color.z)};
   return color;
 }
 

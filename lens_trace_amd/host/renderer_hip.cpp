@@ -63,8 +63,8 @@ void RendererHIP::render(void* pRenderProperties) {
   Camera* pCamera = (Camera*)props->pCamera;
 
   int program = 0;
-  if (lt_hip_program_from_path(props->kernelFilePath.c_str(), &program) != LT_OK) {
-    printf("Kernel Error: no built-in program for %s\n", props->kernelFilePath.c_str());
+  if (lt_hip_resolve_program(context, props->kernelFilePath.c_str(), &program) != LT_OK) {
+    printf("%s\n", lt_hip_last_error(context));   // like the reference's build log (renderer_opencl.cpp:50-53)
     return;
   }
 

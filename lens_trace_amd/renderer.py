@@ -119,6 +119,12 @@ class RendererHIP:
         self._scene_key = None
         self._scene_refs = None
 
+    def resolve_program(self, kernel_file_path):
+        """Built-in program by basename, or a user .hip file compiled with hipRTC at first use and cached by path."""
+        out = ctypes.c_int(0)
+        self._check(self._L.lt_hip_resolve_program(self._ctx, str(kernel_file_path).encode(), ctypes.byref(out)))
+        return out.value
+
     # -- the plugin entry point ----------------------------------------------------------------------
     def render(self, props: RenderPropertiesHIP):
         W, H, D = props.imageDimensions
@@ -130,7 +136,7 @@ class RendererHIP:
         key = (id(a), id(m), _fingerprint([a.nodes, a.prims, m.materials, a.lights]))
         if key != self._scene_key:      # the reference re-uploads on every call; here the upload is cached
             self.set_scene(a, props.pModel)
-        program = C.program_from_path(props.kernelFilePath)
+        program = self.resolve_program(props.kernelFilePath)
         d = make_desc(program, W, H, D, props.pCamera, props.kernelMode, props.frameFirst, props.frameCount,
                       props.accumulate, props.accumulateBase, None, props.giMaxDepth, props.collectStats, props.pixelCounters, props.deviceLibm)
         self._check(self._L.lt_hip_render(self._ctx, ctypes.byref(d), out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
