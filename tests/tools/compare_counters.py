@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-pixel work counters (rays, shadow rays, node visits, triangle tests) of the HIP path vs the
+"""Diagnostic (test infrastructure: uses the oracle): per-pixel work counters (rays, shadow rays, node visits, triangle tests) of the HIP path vs the
 CPU oracle on one golden scene.  Usage: compare_counters.py <scene.ltsb> <program> <W> <H> [frame]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from lens_trace_amd import scene as sc  # noqa: E402
 from lens_trace_amd.renderer import RendererHIP, RenderPropertiesHIP  # noqa: E402

@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from lens_trace_amd import scene as sc  # noqa: E402
 from lens_trace_amd.renderer import RendererHIP, RenderPropertiesHIP  # noqa: E402
