@@ -120,3 +120,217 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(PROGRAM)) void lt_render_ker
                                                           unsigned long long* __restrict__ stats, uint32_t* __restrict__ queues) {
   render_kernel_body<PROGRAM, CFG>(sc, fp, out, stats, queues);
 }
+
+// =====================================================================================================================
+// Wavefront pipeline for the global-illumination programs (gi.cl:241-375): the 16-bounce loop of `shade` as one kernel per
+// stage with ACTIVE-PATH COMPACTION between stages, instead of one lane carrying a pixel through up to 34 rays while its
+// neighbours idle (a path ends at the first occluded light sample or miss; on the Cornell box the mean is 3.9 rays per pixel,
+// the maximum 34).
+//   lt_gi_primary_kernel : camera ray, direct term, first extension ray      -> appends the surviving paths to queue 0
+//   lt_gi_bounce_kernel  : extension ray d of every path in queue d, light sample + shadow ray, indirect term d
+//                                                                             -> appends the surviving paths to queue d+1
+//   lt_gi_resolve_kernel : direct + indirect, the 25-sample blend of the resources/ variant, clamp, running mean, store
+// Queues are structure-of-float4 arrays in HBM (64 bytes per path: origin+film.x, direction, previous normal, {pixel,
+// previous primitive, film.y}); a wave appends with one atomic: ballot of the surviving lanes, popcount, prefix count
+// (mbcnt) for each lane's slot.  All kernels are persistent: a chip-filling grid whose waves pull work (8x8 squares from
+// per-XCD queues / 64-path chunks) with an atomic, the queue length being read from device memory, so the host never waits
+// between stages.  Per pixel the arithmetic and its order are those of the reference loop: the indirect sum receives its
+// terms in depth order, and a path that hits a light adds the terms of all remaining depths at once (the reference
+// re-traces the identical ray each time: same hit, same term).  Used when work is not being counted; the counting variants
+// run the one-lane-per-pixel kernel, which re-traces like the reference does.
+struct GiQueue { float4* o; float4* d; float4* n; uint4* m; };
+
+struct GiParams {
+  GiQueue q[2];            // ping-pong: stage d reads q[d & 1], writes q[(d + 1) & 1]
+  float4* direct;          // per pixel (compact output index): direct colour
+  float4* indirect;        // per pixel: indirect sum so far
+  float4* blend;           // per pixel: running blend of the 25-sample variant
+  uint32_t* counts;        // [maxDepth + 1] queue lengths
+  uint32_t* work;          // [maxDepth + 1] chunk counters of the bounce launches
+  uint32_t sample;         // sampleIndex passed to shade (frameCount, or frameCount*32 + k)
+  uint32_t sampleK;        // k of the 25-sample loop (0 for the single-sample program)
+  uint32_t sampleCount;    // 25 or 1
+};
+
+__device__ __forceinline__ bool square_pixel(const FrameParams& fp, uint32_t b, uint32_t& x, uint32_t& y, uint32_t& pix) {
+  const uint32_t k = b / fp.blocksPerTile, sb = b % fp.blocksPerTile;
+  const uint32_t sbx = sb % fp.blocksPerTileX, sby = sb / fp.blocksPerTileX;
+  const uint32_t tile = fp.tileFirst + k * fp.tileStride;
+  const uint32_t tx = tile % fp.tilesX, ty = tile / fp.tilesX;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lx = sbx * 8u + (lane & 7u), ly = sby * 8u + (lane >> 3);
+  x = tx * fp.tileW + lx;
+  y = ty * fp.tileH + ly;
+  pix = (k * fp.tileH + ly) * fp.tileW + lx;
+  return k < fp.tilesInCall && lx < fp.tileW && ly < fp.tileH && x < fp.width && y < fp.height;
+}
+
+// one atomic per wave: slot of this lane among the lanes with `keep`
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool keep) {
+  const unsigned long long m = __ballot(keep);
+  if (m == 0ull) return 0u;
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if ((int)__lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+  return base + (uint32_t)__popcll(m & ((1ull << __lane_id()) - 1ull));
+}
+
+template <class CFG>
+__global__ __launch_bounds__(kBlock, LT_GI_WAVES) void lt_gi_primary_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t* __restrict__ queues) {
+  extern __shared__ int lds_stack[];
+  Stack<CFG::kDeep> st;
+  st.lds = lds_stack + threadIdx.x;
+  Counters c{};
+  const uint32_t n = fp.totalSquares, q = n / 8u, r = n % 8u;
+  const uint32_t home = __builtin_amdgcn_s_getreg((3u << 11) | 20u) & 7u;
+  for (uint32_t sweep = 0; sweep < 8u;) {
+    const uint32_t xcd = (home + sweep) & 7u;
+    const uint32_t share = q + (xcd < r ? 1u : 0u), start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    uint32_t t = 0;
+    if (threadIdx.x == 0) t = atomicAdd(&queues[xcd], 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t >= share) { sweep++; continue; }
+    uint32_t x, y, pix;
+    const bool valid = square_pixel(fp, start + t, x, y, pix);
+    bool alive = false;
+    V4 position{}, normal{}, dir{};
+    float fx = 0.0f, fy = 0.0f;
+    int prim = 0;
+    if (valid) {
+      const Ray ray = camera_ray<CFG::kDevLibm>(fp, (int)x, (int)y, fx, fy);
+      const uint32_t s = gp.sample;
+      V3 direct{0.0f, 0.0f, 0.0f};
+      Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
+      traverse_camera<kGI, CFG::kDeep, false>(sc, ray, pl, st, c);
+      if (is_light(sc.lights, pl.prim)) {
+        direct = V3{1.0f, 1.0f, 1.0f};
+      } else if (pl.hitType == 1) {
+        const float* pr = prim_ptr(sc, pl.prim);
+        const Material* m = sc.mats + prim_material(pr);
+        float ndotl;
+        if (direct_light<kGI, CFG>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u), 1.0f, position,
+                                   normal, ndotl, st, c)) {
+          direct = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
+        }
+        const V4 hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_(fx, fy, (float)(s + 3u)), random_(fx, fy, (float)(s + 4u)));
+        dir = align_hemisphere<CFG::kDevLibm>(hemi, normal);
+        prim = pl.prim;
+        alive = fp.giMaxDepth > 0;
+      }
+      gp.direct[pix] = make_float4(direct.x, direct.y, direct.z, 0.0f);
+      gp.indirect[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    const uint32_t slot = wave_append(&gp.counts[0], alive);
+    if (alive) {
+      gp.q[0].o[slot] = make_float4(position.x, position.y, position.z, fx);
+      gp.q[0].d[slot] = make_float4(dir.x, dir.y, dir.z, dir.w);
+      gp.q[0].n[slot] = make_float4(normal.x, normal.y, normal.z, normal.w);
+      gp.q[0].m[slot] = make_uint4(pix, (uint32_t)prim, __float_as_uint(fy), 0u);
+    }
+  }
+}
+
+template <class CFG>
+__global__ __launch_bounds__(kBlock, LT_GI_WAVES) void lt_gi_bounce_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t depth) {
+  extern __shared__ int lds_stack[];
+  Stack<CFG::kDeep> st;
+  st.lds = lds_stack + threadIdx.x;
+  Counters c{};
+  const GiQueue in = gp.q[depth & 1u], out = gp.q[(depth + 1u) & 1u];
+  const uint32_t total = gp.counts[depth];
+  const int d = (int)depth;
+  for (;;) {
+    uint32_t chunk = 0;
+    if (threadIdx.x == 0) chunk = atomicAdd(&gp.work[depth], 1u);
+    chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+    if ((uint64_t)chunk * kBlock >= total) break;
+    const uint32_t e = chunk * kBlock + threadIdx.x;
+    bool alive = false;
+    V4 epos{}, enorm{}, ndir{};
+    uint4 misc = make_uint4(0u, 0u, 0u, 0u);
+    float fx = 0.0f;
+    int hitPrim = 0;
+    if (e < total) {
+      const float4 o = in.o[e], dd = in.d[e], nn = in.n[e];
+      misc = in.m[e];
+      fx = o.w;
+      const float fy = __uint_as_float(misc.z);
+      const uint32_t pix = misc.x;
+      const Ray ext{mk4(o.x, o.y, o.z, 1.0f), mk4(dd.x, dd.y, dd.z, dd.w)};
+      const V4 previousNormal = mk4(nn.x, nn.y, nn.z, nn.w);
+      Hit epl{0, 0, kFltMax, 0.0f, 0.0f};
+      traverse<kGI, CFG::kDeep, false, false>(sc, ext, true, (int)misc.y, epl, st, c);
+      const uint32_t s = gp.sample, sd = s + depth;
+      float4 ind = gp.indirect[pix];
+      if (is_light(sc.lights, epl.prim)) {
+        // the reference keeps looping with the SAME ray (gi.cl:319-321): same hit, one more term per remaining depth
+        const float k = dot4(previousNormal, ext.d);
+        for (int dd2 = d; dd2 < fp.giMaxDepth; dd2++) {
+          const float w = (float)(1.0 / (double)(dd2 + 1));
+          ind.x += (w * 1.0f) * k;
+          ind.y += (w * 1.0f) * k;
+          ind.z += (w * 1.0f) * k;
+        }
+        gp.indirect[pix] = ind;
+      } else if (epl.hitType == 1) {
+        const float w = (float)(1.0 / (double)(d + 1));
+        const float* epr = prim_ptr(sc, epl.prim);
+        const Material* em = sc.mats + prim_material(epr);
+        float endotl;
+        if (direct_light<kGI, CFG>(sc, epr, epl.prim, epl.u, epl.v, fx, fy, (float)(sd + 5u), (float)(sd + 6u), (float)(sd + 7u), 1.0f,
+                                   epos, enorm, endotl, st, c)) {
+          ind.x += (w * em->diffuse[0]) * endotl;
+          ind.y += (w * em->diffuse[1]) * endotl;
+          ind.z += (w * em->diffuse[2]) * endotl;
+          gp.indirect[pix] = ind;
+          const V4 hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_(fx, fy, (float)(sd + 8u)), random_(fx, fy, (float)(sd + 9u)));
+          ndir = align_hemisphere<CFG::kDevLibm>(hemi, enorm);
+          hitPrim = epl.prim;
+          alive = d + 1 < fp.giMaxDepth;
+        }
+      }
+    }
+    const uint32_t slot = wave_append(&gp.counts[depth + 1u], alive);
+    if (alive) {
+      out.o[slot] = make_float4(epos.x, epos.y, epos.z, fx);
+      out.d[slot] = make_float4(ndir.x, ndir.y, ndir.z, ndir.w);
+      out.n[slot] = make_float4(enorm.x, enorm.y, enorm.z, enorm.w);
+      out.m[slot] = make_uint4(misc.x, (uint32_t)hitPrim, misc.z, 0u);
+    }
+  }
+}
+
+// direct + indirect (gi.cl:374), the 25-sample blend (resources gi :408-415), clamp (:409-411), running mean, store
+template <class CFG>
+__global__ void lt_gi_resolve_kernel(FrameParams fp, GiParams gp, float* __restrict__ out, uint32_t pixels) {
+  const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= pixels) return;
+  // only pixels inside the image were written by the primary stage
+  const uint32_t perTile = fp.tileW * fp.tileH, k = pix / perTile, rem = pix % perTile, ly = rem / fp.tileW, lx = rem % fp.tileW;
+  const uint32_t tile = fp.tileFirst + k * fp.tileStride, tx = tile % fp.tilesX, ty = tile / fp.tilesX;
+  if (k >= fp.tilesInCall || tx * fp.tileW + lx >= fp.width || ty * fp.tileH + ly >= fp.height) return;
+  const float4 di = gp.direct[pix], in = gp.indirect[pix];
+  V3 color{di.x + in.x, di.y + in.y, di.z + in.z};
+  if (gp.sampleCount > 1u) {
+    if (gp.sampleK > 0u) {
+      const float4 b = gp.blend[pix];
+      const float a = ((float)(25 - (int)gp.sampleK)) / (float)25;
+      color = V3{((1.0f - a) * b.x) + (a * color.x), ((1.0f - a) * b.y) + (a * color.y), ((1.0f - a) * b.z) + (a * color.z)};
+    }
+    if (gp.sampleK + 1u < gp.sampleCount) {
+      gp.blend[pix] = make_float4(color.x, color.y, color.z, 0.0f);
+      return;
+    }
+  }
+  if (fp.clampOutput) color = V3{Math<CFG::kDevLibm>::clamp01(color.x), Math<CFG::kDevLibm>::clamp01(color.y), Math<CFG::kDevLibm>::clamp01(color.z)};
+  float* o = out + (size_t)pix * fp.depth;
+  if (fp.accumulateN <= 0) {
+    o[0] = color.x; o[1] = color.y; o[2] = color.z;
+  } else {
+    const float n = (float)fp.accumulateN, n1 = (float)(fp.accumulateN + 1);
+    o[0] = (color.x + (o[0] * n)) / n1;
+    o[1] = (color.y + (o[1] * n)) / n1;
+    o[2] = (color.z + (o[2] * n)) / n1;
+  }
+}

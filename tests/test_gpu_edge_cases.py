@@ -164,7 +164,8 @@ def test_axis_parallel_and_degenerate_rays(renderer):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_fuzz_random_scenes(renderer, seed):
+def test_fuzz_random_scenes(renderer, monkeypatch, seed):
+    monkeypatch.setenv("LT_GI_MEGAKERNEL", str(seed % 2))       # alternate the two GI execution paths
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(1, 400))
     centre = np.stack([rng.uniform(-4, 4, n), rng.uniform(-1.5, 6.5, n), rng.uniform(-6, 1, n)], axis=-1)

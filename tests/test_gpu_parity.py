@@ -199,3 +199,44 @@ def test_per_pixel_counters_match_oracle_exactly(renderer, scene, prog, W, H, fr
     renderer.render(RenderPropertiesHIP(KERNEL_PATHS[prog], (W, H, 4), out, s, pCamera=cam, pixelCounters=True))
     want = po.pixel_counters(s, cam, W, H, po.PROGRAMS[prog])
     assert np.array_equal(out.astype(np.uint32), want)
+
+
+# ---- both execution paths of the global-illumination programs (wavefront pipeline / one lane per pixel) ----
+@pytest.mark.parametrize("force", ["0", "1"], ids=["wavefront", "megakernel"])
+@pytest.mark.parametrize("prog,W,H,frame,depth", [("global_illumination", 128, 128, 0, 16), ("global_illumination", 97, 61, 5, 3),
+                                                  ("global_illumination", 64, 64, 2, 1), ("global_illumination25", 48, 40, 1, 16)])
+def test_gi_paths_are_bit_identical_to_the_oracle(renderer, monkeypatch, force, prog, W, H, frame, depth):
+    monkeypatch.setenv("LT_GI_MEGAKERNEL", force)
+    s = load("cornell_box_O0")
+    cam = sc.camera_bytes(0.0, 2.5, -50.0, 0.01, 0.0, 0.0, frame)
+    for mode in (KERNEL_MODE_LINEAR, KERNEL_MODE_TILE):
+        got = render(renderer, s, KERNEL_PATHS[prog], W, H, cam, mode, giMaxDepth=depth)
+        want = po.render(s, cam, W, H, po.PROGRAMS[prog], mode, gi_max_depth=depth)
+        assert np.array_equal(got, want)
+    # running mean through the pipeline, and tile sharding of it
+    got = render(renderer, s, KERNEL_PATHS[prog], 64, 48, CAM, frameFirst=1, frameCount=3, accumulate=True, giMaxDepth=depth)
+    acc = np.zeros((48, 64, 3), dtype=np.float32)
+    for i, f in enumerate(range(1, 4)):
+        po.accumulate(acc, po.render(s, sc.camera_with_frame(CAM, f), 64, 48, po.PROGRAMS[prog], gi_max_depth=depth), i)
+    assert np.array_equal(got, acc)
+
+
+@pytest.mark.parametrize("force", ["0", "1"], ids=["wavefront", "megakernel"])
+def test_gi_tile_sharding(renderer, monkeypatch, force):
+    import torch
+    monkeypatch.setenv("LT_GI_MEGAKERNEL", force)
+    s = load("cornell_box_O0")
+    W, H, tile, ranks = 200, 120, (64, 64), 3
+    cam = sc.camera_bytes(0.0, 2.5, -50.0, 0.0, 0.0, 0.0, 3)
+    renderer.set_scene(s)
+    whole = render(renderer, s, KERNEL_PATHS["global_illumination"], W, H, cam)
+    descs = [make_desc(C.PROGRAM_GLOBAL_ILLUMINATION, W, H, 3, cam, tile=(tile[0], tile[1], r, ranks)) for r in range(ranks)]
+    per_rank = max(renderer.output_floats(d) for d in descs)
+    gathered = torch.zeros((ranks, per_rank), dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for r, d in enumerate(descs):
+        renderer.render_device(d, gathered[r].data_ptr(), per_rank * 4, stream)
+    image = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0")
+    renderer.untile(gathered.data_ptr(), per_rank, ranks, W, H, 3, tile[0], tile[1], image.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(image.cpu().numpy(), whole)
