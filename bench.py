@@ -109,7 +109,7 @@ def main():
     r = RendererHIP(local_rank)
     r.set_scene(scene)
 
-    plan = TilePlan(W, H, D, args.tile, args.tile, world)
+    plan = TilePlan.balanced(W, H, D, world, args.tile)
     tile = plan.desc_tile(rank) if world > 1 else None
 
     def desc(stats=False):
@@ -122,8 +122,9 @@ def main():
     per_rank = my_floats if world == 1 else plan.floats_per_rank
     assert my_floats <= per_rank
     mine = torch.zeros(per_rank, dtype=torch.float32, device=dev)
-    gathered = [torch.empty(per_rank, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # the root receives every rank's stack straight into its row of `stack` (rows are contiguous views: no staging copy)
     stack = torch.empty((world, per_rank), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    gathered = [stack[i] for i in range(world)] if stack is not None else None
     image = torch.empty((H, W, D), dtype=torch.float32, device=dev) if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -132,8 +133,7 @@ def main():
         if world > 1:
             dist.gather(mine, gathered, dst=0)
             if rank == 0:
-                torch.stack(gathered, out=stack)
-                r.untile(stack.data_ptr(), per_rank, world, W, H, D, args.tile, args.tile, image.data_ptr(), stream)
+                r.untile(stack.data_ptr(), per_rank, world, W, H, D, plan.tile_w, plan.tile_h, image.data_ptr(), stream)
 
     # ---- reference-algorithm work counts of this rank's share (one untimed pass with device atomics) ----
     step(desc(stats=True))
@@ -143,7 +143,10 @@ def main():
     if world > 1:
         dist.all_reduce(counts)
     rays_total, shadow_total, nodes_total, tris_total, pixels_total = [float(x) for x in counts.tolist()]
-    my_alg_bytes_per_launch = (32.0 * st["node_visits"] + 76.0 * st["tri_tests"]) / args.spp + 36.0 * st["pixels"]
+    # algorithmic bytes of one step of this rank (32 B per node visit, 76 B per triangle test, 12 B per pixel
+    # written + 24 B read-modify-write per accumulated sample), divided below by the render launches the step really made
+    # (one launch per sample, or ONE for all samples when the library fuses them: lt_capi.hip, render_on_stream)
+    my_alg_bytes_per_step = 32.0 * st["node_visits"] + 76.0 * st["tri_tests"] + 36.0 * st["pixels"] * args.spp
 
     for _ in range(args.warmup):
         step(d)
@@ -174,6 +177,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays_total * args.steps / elapsed / 1e6
         launch_ms = kernel_ms / max(launches, 1)
+        launches_per_step = max(launches, 1) / args.steps
+        my_alg_bytes_per_launch = my_alg_bytes_per_step / launches_per_step
         achieved = my_alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
         out = {
             "metric": "Mrays/s (primary+secondary+shadow), 1M-tri @4K",
@@ -192,7 +197,7 @@ def main():
                     "the reference algorithm, whose counts (measured once with the counting kernel) price roofline.achieved",
             "config": {"workload": "%s, %d triangles, %dx%d, %d spp running mean, program %s, %s" % (
                            scene_name, scene.n_prims, W, H, args.spp, args.program,
-                           "whole image on 1 GPU" if world == 1 else "%dx%d tiles interleaved over %d GPUs + 1 RCCL gather" % (args.tile, args.tile, world)),
+                           "whole image on 1 GPU" if world == 1 else "%dx%d tiles interleaved over %d GPUs + 1 RCCL gather" % (plan.tile_w, plan.tile_h, world)),
                        "triangles": scene.n_prims, "bvh_nodes": scene.n_nodes, "width": W, "height": H, "spp": args.spp,
                        "rays_per_frame": rays_total, "node_visits_per_ray": nodes_total / rays_total,
                        "tri_tests_per_ray": tris_total / rays_total, "kernel_only_mrays_per_s": round(rays_total * args.steps / kernel_s / 1e6, 2),
@@ -201,6 +206,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic("%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program)) if world == 1 else None,
                          "kernel": "lt_render_kernel<accumulator>", "launch_ms": round(launch_ms, 4),
+                         "launches_per_step": launches_per_step, "samples_per_launch": args.spp / launches_per_step,
                          "algorithmic_bytes_per_launch": my_alg_bytes_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -43,6 +43,34 @@ __global__ void lt_untile_kernel(const float* __restrict__ gathered, uint64_t fl
   for (uint32_t ch = 0; ch < depth; ch++) dst[ch] = src[ch];
 }
 
+// Folds the n sample images of a fused launch (samples + f * stride, f < n, in frame order) into the running mean held in
+// `out`: accumulator.frag:10-20, `(c + acc*n) / (n+1)` with n = base + f, the same expression in the same order as the
+// read-modify-write of render_square, so the result is bit for bit what n single-sample launches leave behind.  Pixels of
+// edge tiles that lie outside the image are not touched (render_square never writes them).
+__global__ void lt_running_mean_kernel(const float* __restrict__ samples, uint32_t n, uint64_t stride, float* __restrict__ out,
+                                       uint64_t floats, int32_t base, FrameParams fp, int checkPadding) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= floats) return;
+  if (checkPadding) {
+    const uint64_t pix = i / fp.depth, perTile = (uint64_t)fp.tileW * fp.tileH;
+    const uint32_t k = (uint32_t)(pix / perTile), rem = (uint32_t)(pix % perTile);
+    const uint32_t ly = rem / fp.tileW, lx = rem % fp.tileW, tile = fp.tileFirst + k * fp.tileStride;
+    if ((tile % fp.tilesX) * fp.tileW + lx >= fp.width || (tile / fp.tilesX) * fp.tileH + ly >= fp.height) return;
+  }
+  float acc = base > 0 ? out[i] : 0.0f;
+  for (uint32_t f = 0; f < n; f++) {
+    const float c = samples[(uint64_t)f * stride + i];
+    const int32_t N = base + (int32_t)f;
+    if (N <= 0) {
+      acc = c;
+    } else {
+      const float nf = (float)N, n1 = (float)(N + 1);
+      acc = (c + (acc * nf)) / n1;
+    }
+  }
+  out[i] = acc;
+}
+
 // ---------------------------------------------------------------------------------- context
 struct lt_hip_context {
   int device = -1;
@@ -57,6 +85,13 @@ struct lt_hip_context {
   unsigned long long* d_stats = nullptr;
   uint32_t* d_queues = nullptr;      // persistent mode: 8 per-XCD work counters per launch of a call
   uint32_t queue_frames = 0;
+  float* d_samples = nullptr;        // un-accumulated sample images of a fused multi-sample launch
+  uint64_t d_samples_bytes = 0;
+  uint32_t* d_order = nullptr;       // persistent mode: hand-out order of the squares (slow-path squares first), cached
+  uint64_t order_capacity = 0;
+  std::vector<uint32_t> order_key;   // what d_order was built for
+  bool order_natural = false;        // ... and found no slow-path square in (natural order)
+  uint32_t order_head[8] = {0};      // slow-path squares at the head of each XCD's share
   int cu_count = 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
@@ -137,6 +172,8 @@ extern "C" int lt_hip_destroy(lt_hip_context* ctx) {
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
   if (ctx->d_queues) (void)hipFree(ctx->d_queues);
+  if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+  if (ctx->d_order) (void)hipFree(ctx->d_order);
   for (auto& up : ctx->user_programs) (void)hipModuleUnload(up.module);
   for (void*& b : ctx->d_gi) if (b) (void)hipFree(b);
   if (ctx->d_giCtl) (void)hipFree(ctx->d_giCtl);
@@ -441,6 +478,71 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   return LT_OK;
 }
 
+// Hand-out order of the 8x8 squares in persistent mode.  Each XCD keeps its contiguous share of the logical square list
+// (render_kernel_body); inside a share, the squares holding a pixel of the image's centre row (direction.y == 0 exactly) or,
+// with an unrotated camera, centre column (direction.x == 0) come first.  Those wavefronts cannot use the packet walk or the
+// NaN-free box test, and where scene geometry lies in the camera's axis planes (x = camera.x on the 1 M-triangle wall) the
+// reference's NaN semantics make their rays visit every box touching the plane: 1.9 ms for such a square against 0.3 ms
+// for its neighbours.  Started last they are a launch's tail; started first they overlap with everything else.
+static int ensure_square_order(lt_hip_context* ctx, const lt_hip_render_desc* d, const TilePlan& p, bool unrotated, hipStream_t s,
+                               const uint32_t** order, uint32_t head[8]) {
+  *order = nullptr;
+  for (int i = 0; i < 8; i++) head[i] = 0;
+  const int64_t cx = (unrotated && d->width % 2 == 0) ? d->width / 2 : -1, cy = d->height % 2 == 0 ? d->height / 2 : -1;
+  const uint32_t bpt = p.bptx * p.bpty;
+  const uint64_t n = (uint64_t)p.tilesInCall * bpt;
+  if (n == 0 || (cx < 0 && cy < 0)) return LT_OK;
+  const std::vector<uint32_t> key = {d->width, d->height, p.tileW, p.tileH, p.tileFirst, p.tileStride, (uint32_t)cx, (uint32_t)cy};
+  if (key == ctx->order_key) {
+    *order = ctx->order_natural ? nullptr : ctx->d_order;
+    if (*order) for (int i = 0; i < 8; i++) head[i] = ctx->order_head[i];
+    return LT_OK;
+  }
+  std::vector<uint32_t> ord((size_t)n);
+  const uint64_t q = n / 8, r = n % 8;
+  size_t special = 0;
+  for (uint32_t xcd = 0; xcd < 8; xcd++) {
+    const uint64_t share = q + (xcd < r ? 1 : 0), start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    size_t pos = (size_t)start;
+    std::vector<uint32_t> rest;
+    rest.reserve((size_t)share);
+    for (uint64_t b = start; b < start + share; b++) {
+      const uint32_t k = (uint32_t)(b / bpt), sb = (uint32_t)(b % bpt);
+      const uint32_t tile = p.tileFirst + k * p.tileStride;
+      const int64_t x0 = (int64_t)(tile % p.tilesX) * p.tileW + (sb % p.bptx) * 8, y0 = (int64_t)(tile / p.tilesX) * p.tileH + (sb / p.bptx) * 8;
+      // (a square is clipped to its tile: an 8-pixel span that crosses the tile edge does not reach the next tile's pixels)
+      const int64_t x1 = std::min<int64_t>(x0 + 8, (int64_t)(tile % p.tilesX) * p.tileW + p.tileW);
+      const int64_t y1 = std::min<int64_t>(y0 + 8, (int64_t)(tile / p.tilesX) * p.tileH + p.tileH);
+      if ((cx >= x0 && cx < x1) || (cy >= y0 && cy < y1)) ord[pos++] = (uint32_t)b; else rest.push_back((uint32_t)b);
+    }
+    special += pos - (size_t)start;
+    ctx->order_head[xcd] = (uint32_t)(pos - (size_t)start);
+    std::copy(rest.begin(), rest.end(), ord.begin() + pos);
+  }
+  ctx->order_key.clear();
+  if (special == 0) {   // natural order
+    ctx->order_key = key;
+    ctx->order_natural = true;
+    return LT_OK;
+  }
+  if (ctx->order_capacity < n) {
+    if (ctx->d_order) LT_HIP_CHECK(ctx, hipFree(ctx->d_order));
+    ctx->d_order = nullptr;
+    ctx->order_capacity = 0;
+    LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_order, n * sizeof(uint32_t)));
+    ctx->order_capacity = n;
+  }
+  // pageable source: the copy is staged before the call returns, and earlier launches on `s` that read the old order are
+  // ordered before it
+  LT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_order, ord.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  LT_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  ctx->order_key = key;
+  ctx->order_natural = false;
+  *order = ctx->d_order;
+  for (int i = 0; i < 8; i++) head[i] = ctx->order_head[i];
+  return LT_OK;
+}
+
 static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, float* out_device, uint64_t out_bytes, hipStream_t s) {
   if (!ctx) return LT_ERR_INVALID_ARGUMENT;
   if (!ctx->has_scene) return fail(ctx, LT_ERR_NO_SCENE, "lt_hip_render before lt_hip_set_scene");
@@ -514,6 +616,11 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   }
   fp.totalSquares = (uint32_t)nblocks;
   fp.persistent = persistent;
+  fp.order = nullptr;
+  if (persistent && !getenv("LT_NATURAL_ORDER")) {
+    const int orc = ensure_square_order(ctx, d, p, fp.sinYaw == 0.0f, s, &fp.order, fp.orderHead);
+    if (orc) return orc;
+  }
   // The global-illumination programs run as a wavefront pipeline with path compaction when the scene is big enough for the
   // traversal to dominate the ~18 launches and the queue traffic per sample (1 M-triangle wall at 4K, 16 bounces: 42 ms
   // against 64 ms for the one-lane-per-pixel kernel; 42-triangle Cornell box at 1080p: 3.6 ms against 3.0 ms), and never
@@ -528,15 +635,47 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
     const int erc = ensure_gi_buffers(ctx, giPixels);
     if (erc) return erc;
   }
+  // Several samples of a running mean in ONE launch.  A launch cannot end before its slowest wavefront does -- one 8x8 square
+  // is a dependent chain of several hundred node fetches, ~0.3-0.6 ms on the 1 M-triangle scene, 1.9 ms for the squares on
+  // the image's centre column -- so a launch per sample pays that drain once per sample: 0.65 ms of a 4.5 ms launch for the
+  // whole 4K frame, and of a 1.2 ms launch for one GPU's eighth of it.  Fused, the work items are (frame, square) pairs, all
+  // independent: each stores its un-accumulated colour in its frame's slice of a scratch buffer and lt_running_mean_kernel
+  // folds the slices in frame order afterwards (same arithmetic, same order: bit-identical).  LT_FUSED_FRAMES=0 turns it
+  // off (A/B measurements), LT_FUSED_BYTES caps the scratch buffer (default 4 GiB; tests use it to force several chunks).
+  uint32_t chunk = 1;
+  if (persistent && !giWavefront && !stats && frames > 1 && d->accumulate && nblocks > 0) {
+    const char* fe = getenv("LT_FUSED_FRAMES");
+    const char* fb = getenv("LT_FUSED_BYTES");
+    const uint64_t cap = fb ? strtoull(fb, nullptr, 10) : (4ull << 30);
+    const uint64_t frameBytes = p.floats * sizeof(float);
+    if (!(fe && atoi(fe) == 0) && frameBytes > 0)
+      chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)frames, cap / frameBytes, 0xffffffffull / nblocks}));
+    if (chunk > 1 && ctx->d_samples_bytes < chunk * frameBytes) {
+      if (ctx->d_samples) LT_HIP_CHECK(ctx, hipFree(ctx->d_samples));
+      ctx->d_samples = nullptr;
+      ctx->d_samples_bytes = 0;
+      LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_samples, chunk * frameBytes));
+      ctx->d_samples_bytes = chunk * frameBytes;
+    }
+  }
+  const bool fused = chunk > 1;
+  const bool paddedTiles = d->width % p.tileW != 0 || d->height % p.tileH != 0;
   LT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, s));
   uint32_t launches = 0;
   if (nblocks > 0) {
-    for (uint32_t f = 0; f < frames; f++) {
+    uint32_t launchIndex = 0;
+    for (uint32_t f = 0; f < frames; launchIndex++) {
+      const uint32_t nf = fused ? std::min(chunk, frames - f) : 1u;   // frames of this launch
       fp.frameCount = d->frame_count ? d->frame_first + f : camFrame;
-      fp.accumulateN = (d->frame_count && d->accumulate) ? (int32_t)(d->accumulate_base + f) : -1;
+      fp.accumulateN = (d->frame_count && d->accumulate && !fused) ? (int32_t)(d->accumulate_base + f) : -1;
+      fp.fusedFrames = nf;
+      fp.frameStride = fused ? p.floats : 0;
+      float* const out_launch = fused ? ctx->d_samples : out_device;
+      const uint32_t firstFrame = f;
+      f += nf;
       const uint32_t resident = (uint32_t)ctx->cu_count * 32u;   // every wave slot of the chip, once
-      const dim3 grid(persistent ? (uint32_t)std::min<uint64_t>(nblocks, resident) : (uint32_t)nblocks);
-      uint32_t* queues = persistent ? ctx->d_queues + (size_t)f * 8 : nullptr;
+      const dim3 grid(persistent ? (uint32_t)std::min<uint64_t>(nblocks * nf, resident) : (uint32_t)nblocks);
+      uint32_t* queues = persistent ? ctx->d_queues + (size_t)launchIndex * 8 : nullptr;
       // LDS stack rows: with the top entry in a register, the rows below it number at most (interior levels - 1)
       uint32_t lds = (uint32_t)std::max(1, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
@@ -556,22 +695,25 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       if (userProgram) {
         const lt_hip_context::UserProgram& up = ctx->user_programs[d->program - LT_PROGRAM_USER_BASE];
         unsigned long long* statsPtr = ctx->d_stats;
-        float* outPtr = out_device;
+        float* outPtr = out_launch;
         void* args[] = {(void*)&sc, (void*)&fp, (void*)&outPtr, (void*)&statsPtr, (void*)&queues};
         LT_HIP_CHECK(ctx, hipModuleLaunchKernel(deep ? up.deep : up.lds, grid.x, 1, 1, kBlock, 1, 1, lds, s, args, nullptr));
-        launches++;
-        continue;
-      }
-      switch (d->program) {
-        case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
-        case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
-        case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
-        case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
-        case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
-        default: launch_program<kCustom>(lc, grid, lds, s, sc, fp, out_device, ctx->d_stats, queues); break;
+      } else switch (d->program) {
+        case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
+        case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
+        case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
+        case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
+        case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
+        default: launch_program<kCustom>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
       }
       LT_HIP_CHECK(ctx, hipGetLastError());
       launches++;
+      if (fused) {
+        const uint32_t threads = 256;
+        lt_running_mean_kernel<<<dim3((uint32_t)((p.floats + threads - 1) / threads)), dim3(threads), 0, s>>>(
+            ctx->d_samples, nf, p.floats, out_device, p.floats, (int32_t)(d->accumulate_base + firstFrame), fp, paddedTiles ? 1 : 0);
+        LT_HIP_CHECK(ctx, hipGetLastError());
+      }
     }
   }
   LT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, s));

@@ -272,6 +272,7 @@ template <int PROGRAM, bool DEEP, bool STATS, bool FINITE, bool ANYHIT>
 __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool useIgnore, int ignore,
                                      Hit& pl, Stack<DEEP>& st, Counters& c) {
   const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
+  const uint32_t negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);   // dirIsNeg[axis] = bit `axis` (axis <= 2: set_scene)
   const int ign = useIgnore ? ignore : -1;   // leaf offsets are >= 0
   int cur = 0, sp = 0, tos = 0;              // sp entries on the stack, the top one in `tos`
   int pend = -1;
@@ -303,8 +304,7 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
       pend = -1;
     }
     if (hit && count == 0) {
-      const uint32_t axis = (meta >> 16) & 0xffu;
-      const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
+      const bool neg = (negBits >> ((meta >> 16) & 0xffu)) & 1u;
       if (sp > 0) st.push(sp - 1, tos);
       tos = neg ? cur + 1 : off;
       sp++;
@@ -707,6 +707,16 @@ struct FrameParams {
   uint32_t blocksPerTileX, blocksPerTile;   // 8x8-pixel wavefront squares per image tile
   uint32_t totalSquares;                    // tilesInCall * blocksPerTile
   uint32_t persistent;                      // != 0: waves pull squares from per-XCD queues instead of one square per workgroup
+  // several samples in one launch (persistent mode): work item = (frame f, square), frame f uses frameCount + f and stores
+  // its colours, un-accumulated, at out + f * frameStride; lt_running_mean_kernel folds them in frame order afterwards
+  uint32_t fusedFrames;                     // >= 1
+  unsigned long long frameStride;           // floats between the sample images of a fused launch
+  // persistent mode: the order in which an XCD's share of squares is handed out (position -> square index), or null for
+  // the natural order.  The host puts the squares that cannot take the fast path (a pixel with an exactly-zero direction
+  // component: image-centre row / column) at the head of each share -- orderHead[xcd] of them -- and a launch hands out the
+  // head squares of ALL its frames before anything else, so that its longest wavefronts start first.
+  const uint32_t* order;
+  uint32_t orderHead[8];
 };
 
 // Camera ray of pixel (x,y): acc.cl:304-312.
@@ -739,7 +749,8 @@ __device__ V3 user_shade(const SceneDev& sc, const Ray& cameraRay, float filmX, 
 // The body of linearKernel / tileKernel for one pixel, all five programs
 // (acc.cl:314-318, basic.cl:338-342, basic_lighting.cl:309-321, resources gi :408-420).
 template <int PROGRAM, class CFG>
-__device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int x, int y, Stack<CFG::kDeep>& st, Counters& c) {
+__device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, uint32_t frameCount, int x, int y, Stack<CFG::kDeep>& st,
+                                 Counters& c) {
   float fx, fy;
   const Ray ray = camera_ray<CFG::kDevLibm>(fp, x, y, fx, fy);
   V3 color;
@@ -749,14 +760,14 @@ __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, int 
     color = shade_custom<CFG>(sc, ray, st, c);
 #ifdef LT_USER_PROGRAM
   } else if (PROGRAM == kUser) {
-    color = user_shade<CFG>(sc, ray, fx, fy, fp.frameCount, st, c);
+    color = user_shade<CFG>(sc, ray, fx, fy, frameCount, st, c);
 #endif
   } else if (PROGRAM == kAccumulator) {
-    color = shade_lighting<kAccumulator, CFG>(sc, ray, fx, fy, fp.frameCount, st, c);
+    color = shade_lighting<kAccumulator, CFG>(sc, ray, fx, fy, frameCount, st, c);
   } else if (PROGRAM == kGI) {
-    color = shade_gi<CFG>(sc, ray, fx, fy, fp.frameCount, fp.giMaxDepth, st, c);
+    color = shade_gi<CFG>(sc, ray, fx, fy, frameCount, fp.giMaxDepth, st, c);
   } else {
-    const uint32_t base = fp.frameCount * 32u;
+    const uint32_t base = frameCount * 32u;
     for (int k = 0; k < 25; k++) {
       const V3 cn = (PROGRAM == kBasicLighting)
                         ? shade_lighting<kBasicLighting, CFG>(sc, ray, fx, fy, base + (uint32_t)k, st, c)

@@ -19,7 +19,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 // One 8x8 pixel square (logical index b, already XCD-ordered) by one wavefront.
 template <int PROGRAM, class CFG>
 __device__ __forceinline__ void render_square(const SceneDev& sc, const FrameParams& fp, float* __restrict__ out, uint32_t b,
-                                              Stack<CFG::kDeep>& st, Counters& c) {
+                                              uint32_t frame, Stack<CFG::kDeep>& st, Counters& c) {
   constexpr bool STATS = CFG::kStats;
   const uint32_t k = b / fp.blocksPerTile, sb = b % fp.blocksPerTile;
   const uint32_t sbx = sb % fp.blocksPerTileX, sby = sb / fp.blocksPerTileX;
@@ -32,8 +32,8 @@ __device__ __forceinline__ void render_square(const SceneDev& sc, const FramePar
   const bool valid = k < fp.tilesInCall && lx < fp.tileW && ly < fp.tileH && x < fp.width && y < fp.height;
   if (valid) {
     Counters pc{};   // this pixel's own counters (diagnostic output), folded into the lane's totals below
-    const V3 color = shade_pixel<PROGRAM, CFG>(sc, fp, (int)x, (int)y, st, STATS ? pc : c);
-    float* o = out + (((size_t)k * fp.tileH + ly) * fp.tileW + lx) * fp.depth;
+    const V3 color = shade_pixel<PROGRAM, CFG>(sc, fp, fp.frameCount + frame, (int)x, (int)y, st, STATS ? pc : c);
+    float* o = out + (size_t)frame * fp.frameStride + (((size_t)k * fp.tileH + ly) * fp.tileW + lx) * fp.depth;
     if (STATS && fp.pixelCounters) {
       o[0] = (float)pc.rays; o[1] = (float)pc.shadow; o[2] = (float)pc.nodes; o[3] = (float)pc.tris;
     } else if (fp.accumulateN <= 0) {   // overwrite, or first frame of a running mean (`if (frameCount > 0)` guard)
@@ -84,7 +84,7 @@ __device__ __forceinline__ void render_kernel_body(const SceneDev& sc, const Fra
   uint32_t sweep = 0;
   bool done = false;
   while (!done) {
-    uint32_t b;
+    uint32_t b, frame = 0;
     if (!fp.persistent) {
       b = xcd_remap(blockIdx.x, gridDim.x);
       done = true;
@@ -94,13 +94,24 @@ __device__ __forceinline__ void render_kernel_body(const SceneDev& sc, const Fra
       uint32_t t = 0;
       if (threadIdx.x == 0) t = atomicAdd(&queues[xcd], 1u);
       t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-      if (t >= share) {
+      if (t >= share * fp.fusedFrames) {   // (share * fusedFrames < 2^32: checked by the host)
         done = ++sweep >= 8u;
         continue;
       }
+      // frame-major inside the XCD's share (every frame of a square stays on its XCD), the head squares of all frames first
+      const uint32_t head = fp.order ? fp.orderHead[xcd] : 0u;
+      if (t < head * fp.fusedFrames) {
+        frame = t / head;
+        t -= frame * head;
+      } else if (fp.fusedFrames > 1u) {
+        t -= head * fp.fusedFrames;
+        frame = t / (share - head);
+        t = head + (t - frame * (share - head));
+      }
       b = start + t;
+      if (fp.order) b = (uint32_t)__builtin_amdgcn_readfirstlane((int)fp.order[b]);
     }
-    render_square<PROGRAM, CFG>(sc, fp, out, b, st, c);
+    render_square<PROGRAM, CFG>(sc, fp, out, b, frame, st, c);
   }
   if (STATS) {
     atomicAdd(&stats[0], (unsigned long long)c.rays);

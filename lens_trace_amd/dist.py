@@ -20,6 +20,19 @@ class TilePlan:
     tile_h: int
     world: int
 
+    @classmethod
+    def balanced(cls, width, height, depth, world, tile=64):
+        """Tiles of about tile x tile pixels whose round-robin assignment mixes columns and rows over the ranks.
+        Tile t goes to rank t % world = (tx + (tiles_x % world) * ty) % world: when tiles_x shares a factor with world
+        (3840 / 64 = 60 tiles over 8 ranks) a tile column lands on world / gcd ranks only, and cost that is concentrated in
+        one image column -- the centre column of an unrotated camera, see DESIGN.md -- on as few GPUs.  The width is
+        narrowed in steps of 8 pixels (the wavefront square) until tiles_x is coprime to world."""
+        from math import gcd
+        for w in range(tile, 7, -8):
+            if gcd((width + w - 1) // w, world) == 1:
+                return cls(width, height, depth, w, tile, world)
+        return cls(width, height, depth, tile, tile, world)
+
     @property
     def tiles_x(self):
         return (self.width + self.tile_w - 1) // self.tile_w

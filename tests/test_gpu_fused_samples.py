@@ -1,0 +1,134 @@
+"""GPU tests (-m gpu) of the two scheduling features of the persistent render kernel: several samples of a running mean
+in one launch (work items = (frame, square); lt_running_mean_kernel folds the per-frame images afterwards) and the
+hand-out order that starts the slow-path squares (image-centre row / column) first.  Neither may change a single bit:
+every case is compared with the one-launch-per-sample path (LT_FUSED_FRAMES=0, natural order) and, where a CPU oracle
+run is cheap, with the oracle's accumulate (accumulator.frag:10-20)."""
+import os
+
+import numpy as np
+import pytest
+
+from lens_trace_amd import _capi as C
+from lens_trace_amd import scene as sc
+from lens_trace_amd import synth
+from lens_trace_amd.dist import TilePlan, untile_numpy
+from lens_trace_amd.renderer import RendererHIP, RenderPropertiesHIP, make_desc
+from oracle import pyoracle as po
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+ACC = "examples/accumulator/resources/kernels/accumulator.cl"
+GI = "examples/global_illumination/resources/kernels/global_illumination.cl"
+CAM = sc.camera_bytes(0.0, 2.5, -50.0, 0.0, 0.0, 0.0, 1)
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    r = RendererHIP(0)
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def cornell():
+    return sc.load_ltsb(os.path.join(GOLDEN, "cornell_box_O0.ltsb")).validate()
+
+
+def frames(renderer, scene, path, W, H, first, count, base=0, start=None, cam=CAM, **kw):
+    out = np.full((H, W, 3), np.nan, dtype=np.float32) if start is None else start.copy()
+    renderer.render(RenderPropertiesHIP(path, (W, H, 3), out, scene, pCamera=cam, frameFirst=first, frameCount=count, accumulate=True,
+                                        accumulateBase=base, **kw))
+    return out, renderer.stats()
+
+
+@pytest.mark.parametrize("path,W,H,count", [(ACC, 96, 96, 6), (ACC, 131, 77, 5), (GI, 64, 48, 3)])
+def test_fused_launch_equals_one_launch_per_sample(renderer, cornell, monkeypatch, path, W, H, count):
+    monkeypatch.setenv("LT_GI_MEGAKERNEL", "1")   # the wavefront GI pipeline has its own per-sample launches
+    fused, st = frames(renderer, cornell, path, W, H, 1, count)
+    assert st["kernel_launches"] == 1 and st["frames"] == count
+    monkeypatch.setenv("LT_FUSED_FRAMES", "0")
+    monkeypatch.setenv("LT_NATURAL_ORDER", "1")
+    single, st = frames(renderer, cornell, path, W, H, 1, count)
+    assert st["kernel_launches"] == count
+    assert np.array_equal(fused, single)
+
+
+def test_fused_launch_matches_oracle_accumulate(renderer, cornell):
+    W, H = 80, 56
+    got, _ = frames(renderer, cornell, ACC, W, H, 1, 7)
+    acc = np.zeros((H, W, 3), dtype=np.float32)
+    for i, f in enumerate(range(1, 8)):
+        po.accumulate(acc, po.render(cornell, sc.camera_with_frame(CAM, f), W, H, po.ACCUMULATOR), i)
+    assert np.array_equal(got, acc)
+
+
+def test_scratch_cap_splits_the_call_into_chunks(renderer, cornell, monkeypatch):
+    W, H, count = 72, 40, 7
+    whole, st = frames(renderer, cornell, ACC, W, H, 1, count)
+    assert st["kernel_launches"] == 1
+    monkeypatch.setenv("LT_FUSED_BYTES", str(3 * W * H * 3 * 4 + 100))   # room for three sample images: 3 + 3 + 1
+    chunked, st = frames(renderer, cornell, ACC, W, H, 1, count)
+    assert st["kernel_launches"] == 3
+    assert np.array_equal(chunked, whole)
+    monkeypatch.setenv("LT_FUSED_BYTES", "16")                           # not even one image: falls back to single launches
+    single, st = frames(renderer, cornell, ACC, W, H, 1, count)
+    assert st["kernel_launches"] == count
+    assert np.array_equal(single, whole)
+
+
+def test_continuing_a_running_mean_across_fused_calls(renderer, cornell):
+    W, H = 64, 64
+    whole, _ = frames(renderer, cornell, ACC, W, H, 1, 9)
+    part, _ = frames(renderer, cornell, ACC, W, H, 1, 4)
+    part, _ = frames(renderer, cornell, ACC, W, H, 5, 5, base=4, start=part)
+    assert np.array_equal(part, whole)
+    # frame 0 first: the reference's `if (frameCount > 0)` guard makes sample 0 an overwrite, whatever the buffer held
+    a, _ = frames(renderer, cornell, ACC, W, H, 0, 3)
+    b, _ = frames(renderer, cornell, ACC, W, H, 0, 3, start=np.full((H, W, 3), 123.0, dtype=np.float32))
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("W,H,tile,ranks", [(200, 120, (64, 64), 3), (100, 70, (56, 16), 2), (96, 64, (96, 8), 4)])
+def test_fused_tile_stacks_keep_their_padding_untouched(renderer, cornell, W, H, tile, ranks):
+    import torch
+    renderer.set_scene(cornell)
+    whole, _ = frames(renderer, cornell, ACC, W, H, 1, 5)
+    plan = TilePlan(W, H, 3, tile[0], tile[1], ranks)
+    stream = torch.cuda.current_stream().cuda_stream
+    stacks = []
+    for r in range(ranks):
+        d = make_desc(C.PROGRAM_ACCUMULATOR, W, H, 3, CAM, frame_first=1, frame_count=5, accumulate=True, accumulate_base=0,
+                      tile=plan.desc_tile(r))
+        buf = torch.full((plan.floats_per_rank,), -7.0, dtype=torch.float32, device="cuda:0")
+        renderer.render_device(d, buf.data_ptr(), plan.floats_per_rank * 4, stream)
+        torch.cuda.synchronize()
+        stacks.append(buf.cpu().numpy())
+    assert np.array_equal(untile_numpy(plan, stacks), whole)
+    # every float of a stack is either a pixel of the image or still the sentinel
+    for r in range(ranks):
+        view = stacks[r].reshape(-1, plan.tile_h, plan.tile_w, 3)
+        inside = np.zeros(view.shape[:3], dtype=bool)
+        for k, t in enumerate(plan.tiles_of(r)):
+            x0, y0, w, h = plan.tile_rect(t)
+            inside[k, :h, :w] = True
+        assert np.all(view[~inside] == -7.0)
+
+
+@pytest.mark.parametrize("yaw", [0.0, 0.3])
+def test_hand_out_order_does_not_change_pixels(renderer, monkeypatch, yaw):
+    # a scene whose geometry lies in the camera's axis planes (grid lines at x = 0 and y = 2.5): the centre column / row rays
+    # take the NaN-keeping box test and visit several times more nodes than their neighbours
+    scene = synth.heightfield_wall(96).validate()
+    cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, 1)
+    W, H = 256, 144
+    ordered, _ = frames(renderer, scene, ACC, W, H, 1, 4, cam=cam)
+    monkeypatch.setenv("LT_NATURAL_ORDER", "1")
+    natural, _ = frames(renderer, scene, ACC, W, H, 1, 4, cam=cam)
+    assert np.array_equal(ordered, natural)
+    monkeypatch.setenv("LT_PERSISTENT", "0")
+    dispatched, _ = frames(renderer, scene, ACC, W, H, 1, 4, cam=cam)
+    assert np.array_equal(ordered, dispatched)
+    want = np.zeros((H, W, 3), dtype=np.float32)
+    for i, f in enumerate(range(1, 5)):
+        po.accumulate(want, po.render(scene, sc.camera_with_frame(cam, f), W, H, po.ACCUMULATOR), i)
+    assert np.array_equal(ordered, want)
