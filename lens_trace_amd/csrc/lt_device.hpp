@@ -164,12 +164,15 @@ __device__ __forceinline__ bool intersect_triangle_data(const float4 t0, const f
   V4 v0v2 = mk4(t1.z, t1.w, t2.x, 0.0f);
   V4 pvec = cross4(ray.d, v0v2);
   float det = dot4(v0v1, pvec);
+  // The double compares of the reference, `(double)fabs(det) < 1e-7` and `< 1e-4`, as float compares against the smallest
+  // float that is >= the double constant (0x33d6bf95, 0x38d1b718): for a float x, (double)x < c  <=>  x < that float.  Exact
+  // (tests/test_capi_cpu.py checks the two constants), and one v_cmp_lt_f32 instead of v_cvt_f64_f32 + v_cmp_lt_f64.
   if (PROGRAM == kBasic || PROGRAM == kCustom) {
     if (__builtin_fabsf(det) < 0.0000001f) return false;
   } else if (PROGRAM == kBasicLighting) {
-    if ((double)__builtin_fabsf(det) < 0.0000001) return false;
+    if (__builtin_fabsf(det) < __uint_as_float(0x33d6bf95u)) return false;
   } else {
-    if ((double)__builtin_fabsf(det) < 0.0001) return false;
+    if (__builtin_fabsf(det) < __uint_as_float(0x38d1b718u)) return false;
   }
   float invDet = 1.0f / det;
   V4 tvec = sub4(ray.o, A);
@@ -254,17 +257,15 @@ __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float 
                 : box_test_reference(lox, loy, loz, hix, hiy, hiz, ray, ix, iy, iz, nx, ny, nz);
 }
 
-#ifndef LT_TRI_BATCH
-#define LT_TRI_BATCH 16     // run the deferred triangle test when this many lanes hold a leaf (or when one must flush)
-#endif
-
-// One node per iteration.  What the round-1 ablations showed: the loop is latency-bound (VALU has ~40 % slack, +27 %
-// VALU costs 5 %; removing the triangle test gains 18 %), so the dependency chain per node is what matters:
-//  * a leaf found in iteration i is only *noted* (`pend`); its triangle loads are issued in iteration i+1 right
-//    behind the next node's loads and both latencies overlap.  Exact: the reference's traversal never reads the
-//    payload (no clipping against payload.t, acc.cl:113-130), and a lane still tests its leaves in reference order;
-//  * the top of the stack is kept in a register (`tos`), LDS holds the entries below it: a pop needs no LDS
-//    round trip before the next node's address is known (the reload of `tos` is off the critical path).
+// One node per iteration, as few instructions as possible (since launches stopped being dominated by their slowest
+// wavefront -- several samples per launch, lt_capi.hip -- the loop is bound by vector-instruction issue: VALU busy 97 %):
+//  * a leaf found in iteration i is only *noted* (`pend`); its triangle is fetched and tested at the top of iteration i+1,
+//    right behind the issue of the next node's loads, so both latencies overlap (testing it inside iteration i costs 25 %).
+//    Exact: the reference's traversal never reads the payload (no clipping against payload.t, acc.cl:113-130), and a lane
+//    still tests its leaves in reference order;
+//  * the stack is plain: push and pop go to the lane's LDS column.  (Under one launch per sample, where the chain per node
+//    mattered more than the instruction count, keeping the top entry in a register and batching the triangle tests until
+//    16 lanes held one were each worth a few per cent; with fused launches they cost 5 % and 2-6 %.)
 // ANYHIT (shadow rays, only when not counting work): the callers of a shadow ray read nothing but `hitType == 0`
 // (acc.cl:276, gi.cl:295,:351), so the walk may stop at the first accepted triangle -- same pixels, fewer node visits
 // than the reference algorithm performs.  The counting (STATS) instantiations never use it.
@@ -274,7 +275,7 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
   const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
   const uint32_t negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);   // dirIsNeg[axis] = bit `axis` (axis <= 2: set_scene)
   const int ign = useIgnore ? ignore : -1;   // leaf offsets are >= 0
-  int cur = 0, sp = 0, tos = 0;              // sp entries on the stack, the top one in `tos`
+  int cur = 0, sp = 0;
   int pend = -1;
   uint32_t pendCount = 0;
   bool alive = true;
@@ -290,10 +291,7 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
     const int off = __float_as_int(b.z);
     const uint32_t count = meta & 0xffffu;
     const bool newLeaf = hit && count != 0 && off != ign;
-    // flush the noted leaf when enough lanes hold one, or when a lane that holds one has found the next
-    const bool flush = LT_TRI_BATCH <= 1 ? true
-                                         : (__popcll(__ballot(pend >= 0)) >= LT_TRI_BATCH || __any(pend >= 0 && newLeaf));
-    if (flush && pend >= 0) {
+    if (pend >= 0) {   // the leaf noted in the previous iteration
       LT_WAVE_COUNT(wTri);
       if (STATS) c.tris += pendCount;    // the reference *calls* intersectTriangle primitiveCount times
       if (intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl)) {
@@ -305,8 +303,7 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
     }
     if (hit && count == 0) {
       const bool neg = (negBits >> ((meta >> 16) & 0xffu)) & 1u;
-      if (sp > 0) st.push(sp - 1, tos);
-      tos = neg ? cur + 1 : off;
+      st.push(sp, neg ? cur + 1 : off);
       sp++;
       cur = neg ? off : cur + 1;
     } else {
@@ -317,9 +314,8 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
       if (sp == 0) {
         alive = false;
       } else {
-        cur = tos;
         sp--;
-        if (sp > 0) tos = st.pop(sp - 1);
+        cur = st.pop(sp);
       }
     }
   }

@@ -58,3 +58,21 @@ def test_output_floats_and_desc_validation():
     d = make_desc(C.PROGRAM_BASIC, 100, 100, 3, cam)
     d.struct_size = 8
     assert L.lt_hip_output_floats(ctypes.byref(d), ctypes.byref(n)) == C.LT_ERR_INVALID_ARGUMENT
+
+
+def test_float_thresholds_equal_the_double_epsilon_compares():
+    """intersect_triangle_data (lt_device.hpp) replaces the reference's `(double)fabs(det) < 1e-4` / `< 1e-7`
+    (accumulator.cl:84, basic_lighting.cl:4) by float compares against 0x38d1b718 / 0x33d6bf95: the smallest floats
+    that are >= the double constants.  For every float x, (double)x < c must equal x < threshold."""
+    import numpy as np
+    src = open(os.path.join(ROOT, "lens_trace_amd", "csrc", "lt_device.hpp")).read()
+    for eps, bits in ((0.0001, 0x38d1b718), (0.0000001, 0x33d6bf95)):
+        assert ("0x%08xu" % bits) in src
+        thr = np.array([bits], dtype=np.uint32).view(np.float32)[0]
+        assert float(thr) >= eps and float(np.nextafter(thr, np.float32(0))) < eps
+        x = (np.arange(-5000, 5001, dtype=np.int64) + bits).astype(np.uint32).view(np.float32)
+        assert np.array_equal(x.astype(np.float64) < eps, x < thr)
+    for x in (np.float32(0), np.float32(1e-30), np.float32(1), np.float32(np.inf), np.float32(np.nan)):
+        for eps, bits in ((0.0001, 0x38d1b718), (0.0000001, 0x33d6bf95)):
+            thr = np.array([bits], dtype=np.uint32).view(np.float32)[0]
+            assert (float(x) < eps) == bool(x < thr)
