@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define LT_HIP_ABI_VERSION 1
+#define LT_HIP_ABI_VERSION 2
 
 typedef struct lt_hip_context lt_hip_context;
 
@@ -123,6 +123,8 @@ typedef struct lt_hip_stats {
   uint32_t kernel_launches;
   float kernel_ms;              /* HIP-event time over the kernels of the last call, on the call's stream */
   float total_ms;               /* lt_hip_render only: upload + kernels + read-back wall time */
+  float render_ms;              /* kernel_ms without the running-mean kernels that follow fused multi-sample launches */
+  uint32_t reserved;
 } lt_hip_stats;
 
 int lt_hip_abi_version(void);

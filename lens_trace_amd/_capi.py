@@ -39,7 +39,8 @@ class RenderDesc(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [("rays", ctypes.c_uint64), ("shadow_rays", ctypes.c_uint64), ("node_visits", ctypes.c_uint64),
                 ("tri_tests", ctypes.c_uint64), ("pixels", ctypes.c_uint64), ("frames", ctypes.c_uint32),
-                ("kernel_launches", ctypes.c_uint32), ("kernel_ms", ctypes.c_float), ("total_ms", ctypes.c_float)]
+                ("kernel_launches", ctypes.c_uint32), ("kernel_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
+                ("render_ms", ctypes.c_float), ("reserved", ctypes.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -90,7 +91,7 @@ def load():
     for name in EXPORTS:
         if name not in ("lt_hip_last_error",):
             getattr(L, name).restype = i32
-    if L.lt_hip_abi_version() != 1:
+    if L.lt_hip_abi_version() != 2:
         raise ImportError("liblenstrace-hip.so ABI version mismatch")
     _lib = L
     return L
