@@ -454,6 +454,7 @@ static int ensure_gi_buffers(lt_hip_context* ctx, uint64_t pixels) {
 template <class CFG>
 static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& sc, const FrameParams& fp, float* out, uint32_t lds,
                             uint64_t pixels, uint32_t sample, uint32_t sampleK, uint32_t sampleCount, uint32_t& launches) {
+  // `pixels` = compact output pixels of ONE frame; fp.fusedFrames frames travel through each launch together
   GiParams gp{};
   for (int k = 0; k < 2; k++) {
     gp.q[k].o = (float4*)ctx->d_gi[4 * k + 0]; gp.q[k].d = (float4*)ctx->d_gi[4 * k + 1];
@@ -464,9 +465,11 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   gp.counts = ctx->d_giCtl + 8;
   gp.work = ctx->d_giCtl + 8 + (kMaxStack + 2);
   gp.sample = sample; gp.sampleK = sampleK; gp.sampleCount = sampleCount;
+  gp.pixels = (uint32_t)pixels;
+  const uint64_t vpixels = pixels * fp.fusedFrames;
   LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_giCtl, 0, kGiCtlWords * sizeof(uint32_t), s));
   const uint32_t resident = (uint32_t)ctx->cu_count * 4u * LT_GI_WAVES;
-  const uint32_t gridA = (uint32_t)std::min<uint64_t>(fp.totalSquares, resident);
+  const uint32_t gridA = (uint32_t)std::min<uint64_t>((uint64_t)fp.totalSquares * fp.fusedFrames, resident);
   hipLaunchKernelGGL((lt_gi_primary_kernel<CFG>), dim3(gridA), dim3(kBlock), lds, s, sc, fp, gp, queues);
   LT_HIP_CHECK(ctx, hipGetLastError());
   launches++;
@@ -475,7 +478,7 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
     LT_HIP_CHECK(ctx, hipGetLastError());
     launches++;
   }
-  hipLaunchKernelGGL((lt_gi_resolve_kernel<CFG>), dim3((uint32_t)((pixels + 255) / 256)), dim3(256), 0, s, fp, gp, out, (uint32_t)pixels);
+  hipLaunchKernelGGL((lt_gi_resolve_kernel<CFG>), dim3((uint32_t)((vpixels + 255) / 256)), dim3(256), 0, s, fp, gp, out, (uint32_t)vpixels);
   LT_HIP_CHECK(ctx, hipGetLastError());
   launches++;
   return LT_OK;
@@ -625,34 +628,39 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
     if (orc) return orc;
   }
   // The global-illumination programs run as a wavefront pipeline with path compaction when the scene is big enough for the
-  // traversal to dominate the ~18 launches and the queue traffic per sample (1 M-triangle wall at 4K, 16 bounces: 42 ms
-  // against 64 ms for the one-lane-per-pixel kernel; 42-triangle Cornell box at 1080p: 3.6 ms against 3.0 ms), and never
-  // when work is being counted (the counting kernels re-trace like the reference does).  LT_GI_MEGAKERNEL=1 / =0 force
-  // one or the other (A/B measurements, tests of both paths on small scenes).
+  // traversal to dominate the ~18 launches and the queue traffic per sample (1 M-triangle wall at 4K, 16 bounces: 34 ms
+  // against 52 ms for the one-lane-per-pixel kernel; 42-triangle Cornell box at 1080p: 3.5 ms against 2.7 ms), or when the
+  // launches serve many frames at once and paths are long (Cornell 1080p, 16 frames per call: 1.50 ms against 1.95 ms per
+  // sample at 16 bounces, but 1.12 against 0.82 ms at 4), and never when work is being counted (the counting kernels
+  // re-trace like the reference does).  LT_GI_MEGAKERNEL=1 / =0 force one or the other (A/B measurements, tests of both
+  // paths on small scenes).
   const char* ge = getenv("LT_GI_MEGAKERNEL");
   const bool giProgram = d->program == LT_PROGRAM_GLOBAL_ILLUMINATION || d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25;
-  const bool giWavefront = giProgram && !stats && nblocks > 0 && (ge ? atoi(ge) == 0 : ctx->n_prims >= 1024u);
+  const bool giManyLongPaths = d->program == LT_PROGRAM_GLOBAL_ILLUMINATION && frames > 1 && d->accumulate && fp.giMaxDepth > 8;
+  const bool giWavefront = giProgram && !stats && nblocks > 0 && (ge ? atoi(ge) == 0 : (ctx->n_prims >= 1024u || giManyLongPaths));
   const uint64_t giPixels = (uint64_t)p.tilesInCall * p.tileW * p.tileH;
-  if (giWavefront) {
-    if (giPixels > 0xffffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many pixels for the GI path queues");
-    const int erc = ensure_gi_buffers(ctx, giPixels);
-    if (erc) return erc;
-  }
+  if (giWavefront && giPixels > 0xffffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many pixels for the GI path queues");
   // Several samples of a running mean in ONE launch.  A launch cannot end before its slowest wavefront does -- one 8x8 square
   // is a dependent chain of several hundred node fetches, ~0.3-0.6 ms on the 1 M-triangle scene, 1.9 ms for the squares on
   // the image's centre column -- so a launch per sample pays that drain once per sample: 0.65 ms of a 4.5 ms launch for the
   // whole 4K frame, and of a 1.2 ms launch for one GPU's eighth of it.  Fused, the work items are (frame, square) pairs, all
   // independent: each stores its un-accumulated colour in its frame's slice of a scratch buffer and lt_running_mean_kernel
   // folds the slices in frame order afterwards (same arithmetic, same order: bit-identical).  LT_FUSED_FRAMES=0 turns it
-  // off (A/B measurements), LT_FUSED_BYTES caps the scratch buffer (default 4 GiB; tests use it to force several chunks).
+  // off (A/B measurements), LT_FUSED_BYTES caps the scratch memory (default 16 GiB of the 288; tests use it to force chunks).
+  // The wavefront GI pipeline fuses the same way (single-sample program only: the 25-sample blend is sequential per pixel):
+  // its ~18 stage launches then serve all frames of a chunk, each path carrying its frame; its per-frame scratch is the path
+  // queues and the direct / indirect images (11 arrays of 16 bytes per pixel) besides the sample image.
   uint32_t chunk = 1;
-  if (persistent && !giWavefront && !stats && frames > 1 && d->accumulate && nblocks > 0) {
+  const bool giFusable = giWavefront && d->program == LT_PROGRAM_GLOBAL_ILLUMINATION;
+  if ((giFusable || (persistent && !giWavefront)) && !stats && frames > 1 && d->accumulate && nblocks > 0) {
     const char* fe = getenv("LT_FUSED_FRAMES");
     const char* fb = getenv("LT_FUSED_BYTES");
-    const uint64_t cap = fb ? strtoull(fb, nullptr, 10) : (4ull << 30);
+    const uint64_t cap = fb ? strtoull(fb, nullptr, 10) : (16ull << 30);
     const uint64_t frameBytes = p.floats * sizeof(float);
+    const uint64_t scratchPerFrame = frameBytes + (giFusable ? giPixels * 16 * 11 : 0);
     if (!(fe && atoi(fe) == 0) && frameBytes > 0)
-      chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)frames, cap / frameBytes, 0xffffffffull / nblocks}));
+      chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)frames, cap / scratchPerFrame, 0xffffffffull / nblocks,
+                                                                  giFusable ? 0xffffffffull / std::max<uint64_t>(giPixels, 1) : ~0ull}));
     if (chunk > 1 && ctx->d_samples_bytes < chunk * frameBytes) {
       if (ctx->d_samples) LT_HIP_CHECK(ctx, hipFree(ctx->d_samples));
       ctx->d_samples = nullptr;
@@ -662,6 +670,10 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
     }
   }
   const bool fused = chunk > 1;
+  if (giWavefront) {
+    const int erc = ensure_gi_buffers(ctx, giPixels * chunk);
+    if (erc) return erc;
+  }
   const bool paddedTiles = d->width % p.tileW != 0 || d->height % p.tileH != 0;
   ctx->mean_pairs = 0;
   LT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, s));
@@ -688,15 +700,14 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         for (uint32_t k = 0; k < samples; k++) {
           const uint32_t sample = samples > 1 ? fp.frameCount * 32u + k : fp.frameCount;
           int grc;
-          if (deep) grc = devlibm ? launch_gi_sample<Config<true, false, true>>(ctx, s, sc, fp, out_device, lds, giPixels, sample, k, samples, launches)
-                                  : launch_gi_sample<Config<true, false, false>>(ctx, s, sc, fp, out_device, lds, giPixels, sample, k, samples, launches);
-          else grc = devlibm ? launch_gi_sample<Config<false, false, true>>(ctx, s, sc, fp, out_device, lds, giPixels, sample, k, samples, launches)
-                             : launch_gi_sample<Config<false, false, false>>(ctx, s, sc, fp, out_device, lds, giPixels, sample, k, samples, launches);
+          if (deep) grc = devlibm ? launch_gi_sample<Config<true, false, true>>(ctx, s, sc, fp, out_launch, lds, giPixels, sample, k, samples, launches)
+                                  : launch_gi_sample<Config<true, false, false>>(ctx, s, sc, fp, out_launch, lds, giPixels, sample, k, samples, launches);
+          else grc = devlibm ? launch_gi_sample<Config<false, false, true>>(ctx, s, sc, fp, out_launch, lds, giPixels, sample, k, samples, launches)
+                             : launch_gi_sample<Config<false, false, false>>(ctx, s, sc, fp, out_launch, lds, giPixels, sample, k, samples, launches);
           if (grc) return grc;
         }
-        continue;
-      }
-      if (userProgram) {
+        launches--;   // (counted again below)
+      } else if (userProgram) {
         const lt_hip_context::UserProgram& up = ctx->user_programs[d->program - LT_PROGRAM_USER_BASE];
         unsigned long long* statsPtr = ctx->d_stats;
         float* outPtr = out_launch;

@@ -158,9 +158,12 @@ struct GiParams {
   float4* blend;           // per pixel: running blend of the 25-sample variant
   uint32_t* counts;        // [maxDepth + 1] queue lengths
   uint32_t* work;          // [maxDepth + 1] chunk counters of the bounce launches
-  uint32_t sample;         // sampleIndex passed to shade (frameCount, or frameCount*32 + k)
+  uint32_t sample;         // sampleIndex passed to shade (frameCount, or frameCount*32 + k) of the launch's first frame
   uint32_t sampleK;        // k of the 25-sample loop (0 for the single-sample program)
   uint32_t sampleCount;    // 25 or 1
+  // Several frames per set of launches (single-sample program only; FrameParams::fusedFrames of them): frame f uses sample
+  // + f, its pixels live at [f * pixels, (f + 1) * pixels) of direct / indirect, and every path carries its frame (m.w).
+  uint32_t pixels;         // compact output pixels of one frame
 };
 
 __device__ __forceinline__ bool square_pixel(const FrameParams& fp, uint32_t b, uint32_t& x, uint32_t& y, uint32_t& pix) {
@@ -201,16 +204,19 @@ __global__ __launch_bounds__(kBlock, LT_GI_WAVES) void lt_gi_primary_kernel(Scen
     uint32_t t = 0;
     if (threadIdx.x == 0) t = atomicAdd(&queues[xcd], 1u);
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-    if (t >= share) { sweep++; continue; }
+    if (t >= share * fp.fusedFrames) { sweep++; continue; }
+    const uint32_t frame = t / share;   // frame-major inside the XCD's share
+    t -= frame * share;
     uint32_t x, y, pix;
     const bool valid = square_pixel(fp, start + t, x, y, pix);
+    pix += frame * gp.pixels;
     bool alive = false;
     V4 position{}, normal{}, dir{};
     float fx = 0.0f, fy = 0.0f;
     int prim = 0;
     if (valid) {
       const Ray ray = camera_ray<CFG::kDevLibm>(fp, (int)x, (int)y, fx, fy);
-      const uint32_t s = gp.sample;
+      const uint32_t s = gp.sample + frame;
       V3 direct{0.0f, 0.0f, 0.0f};
       Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
       traverse_camera<kGI, CFG::kDeep, false>(sc, ray, pl, st, c);
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_WAVES) void lt_gi_primary_kernel(Scen
       gp.q[0].o[slot] = make_float4(position.x, position.y, position.z, fx);
       gp.q[0].d[slot] = make_float4(dir.x, dir.y, dir.z, dir.w);
       gp.q[0].n[slot] = make_float4(normal.x, normal.y, normal.z, normal.w);
-      gp.q[0].m[slot] = make_uint4(pix, (uint32_t)prim, __float_as_uint(fy), 0u);
+      gp.q[0].m[slot] = make_uint4(pix, (uint32_t)prim, __float_as_uint(fy), frame);
     }
   }
 }
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_WAVES) void lt_gi_bounce_kernel(Scene
       const V4 previousNormal = mk4(nn.x, nn.y, nn.z, nn.w);
       Hit epl{0, 0, kFltMax, 0.0f, 0.0f};
       traverse<kGI, CFG::kDeep, false, false>(sc, ext, true, (int)misc.y, epl, st, c);
-      const uint32_t s = gp.sample, sd = s + depth;
+      const uint32_t s = gp.sample + misc.w, sd = s + depth;
       float4 ind = gp.indirect[pix];
       if (is_light(sc.lights, epl.prim)) {
         // the reference keeps looping with the SAME ray (gi.cl:319-321): same hit, one more term per remaining depth
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_WAVES) void lt_gi_bounce_kernel(Scene
       out.o[slot] = make_float4(epos.x, epos.y, epos.z, fx);
       out.d[slot] = make_float4(ndir.x, ndir.y, ndir.z, ndir.w);
       out.n[slot] = make_float4(enorm.x, enorm.y, enorm.z, enorm.w);
-      out.m[slot] = make_uint4(misc.x, (uint32_t)hitPrim, misc.z, 0u);
+      out.m[slot] = make_uint4(misc.x, (uint32_t)hitPrim, misc.z, misc.w);
     }
   }
 }
@@ -315,13 +321,14 @@ __global__ __launch_bounds__(kBlock, LT_GI_WAVES) void lt_gi_bounce_kernel(Scene
 // direct + indirect (gi.cl:374), the 25-sample blend (resources gi :408-415), clamp (:409-411), running mean, store
 template <class CFG>
 __global__ void lt_gi_resolve_kernel(FrameParams fp, GiParams gp, float* __restrict__ out, uint32_t pixels) {
-  const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= pixels) return;
+  const uint32_t vpix = blockIdx.x * blockDim.x + threadIdx.x;   // (frame, pixel) of a fused launch
+  if (vpix >= pixels) return;
+  const uint32_t frame = vpix / gp.pixels, pix = vpix - frame * gp.pixels;
   // only pixels inside the image were written by the primary stage
   const uint32_t perTile = fp.tileW * fp.tileH, k = pix / perTile, rem = pix % perTile, ly = rem / fp.tileW, lx = rem % fp.tileW;
   const uint32_t tile = fp.tileFirst + k * fp.tileStride, tx = tile % fp.tilesX, ty = tile / fp.tilesX;
   if (k >= fp.tilesInCall || tx * fp.tileW + lx >= fp.width || ty * fp.tileH + ly >= fp.height) return;
-  const float4 di = gp.direct[pix], in = gp.indirect[pix];
+  const float4 di = gp.direct[vpix], in = gp.indirect[vpix];
   V3 color{di.x + in.x, di.y + in.y, di.z + in.z};
   if (gp.sampleCount > 1u) {
     if (gp.sampleK > 0u) {
@@ -335,7 +342,7 @@ __global__ void lt_gi_resolve_kernel(FrameParams fp, GiParams gp, float* __restr
     }
   }
   if (fp.clampOutput) color = V3{Math<CFG::kDevLibm>::clamp01(color.x), Math<CFG::kDevLibm>::clamp01(color.y), Math<CFG::kDevLibm>::clamp01(color.z)};
-  float* o = out + (size_t)pix * fp.depth;
+  float* o = out + (size_t)frame * fp.frameStride + (size_t)pix * fp.depth;   // fused: this frame's un-accumulated slice
   if (fp.accumulateN <= 0) {
     o[0] = color.x; o[1] = color.y; o[2] = color.z;
   } else {

@@ -132,3 +132,43 @@ def test_hand_out_order_does_not_change_pixels(renderer, monkeypatch, yaw):
     for i, f in enumerate(range(1, 5)):
         po.accumulate(want, po.render(scene, sc.camera_with_frame(cam, f), W, H, po.ACCUMULATOR), i)
     assert np.array_equal(ordered, want)
+
+
+# ---- the wavefront GI pipeline: all frames of a call through one set of stage launches ----
+@pytest.mark.parametrize("W,H,count,depth", [(64, 48, 4, 16), (97, 61, 3, 3)])
+def test_wavefront_gi_fused_frames(renderer, cornell, monkeypatch, W, H, count, depth):
+    monkeypatch.setenv("LT_GI_MEGAKERNEL", "0")
+    fused, st = frames(renderer, cornell, GI, W, H, 1, count, giMaxDepth=depth)
+    assert st["kernel_launches"] == depth + 2          # primary + one per bounce + resolve, for all frames together
+    monkeypatch.setenv("LT_FUSED_FRAMES", "0")
+    single, st = frames(renderer, cornell, GI, W, H, 1, count, giMaxDepth=depth)
+    assert st["kernel_launches"] == count * (depth + 2)
+    assert np.array_equal(fused, single)
+    want = np.zeros((H, W, 3), dtype=np.float32)
+    for i, f in enumerate(range(1, count + 1)):
+        po.accumulate(want, po.render(cornell, sc.camera_with_frame(CAM, f), W, H, po.GI, gi_max_depth=depth), i)
+    assert np.array_equal(fused, want)
+
+
+def test_wavefront_gi_fused_chunks_and_tiles(renderer, cornell, monkeypatch):
+    import torch
+    monkeypatch.setenv("LT_GI_MEGAKERNEL", "0")
+    W, H, count, depth = 100, 70, 5, 4
+    whole, _ = frames(renderer, cornell, GI, W, H, 1, count, giMaxDepth=depth)
+    per_frame = W * H * (3 * 4 + 16 * 11)
+    monkeypatch.setenv("LT_FUSED_BYTES", str(2 * per_frame + 64))     # two frames per chunk: 2 + 2 + 1
+    chunked, st = frames(renderer, cornell, GI, W, H, 1, count, giMaxDepth=depth)
+    assert st["kernel_launches"] == 3 * (depth + 2)
+    assert np.array_equal(chunked, whole)
+    monkeypatch.delenv("LT_FUSED_BYTES")
+    plan = TilePlan(W, H, 3, 48, 32, 3)
+    stream = torch.cuda.current_stream().cuda_stream
+    stacks = []
+    for r in range(plan.world):
+        d = make_desc(C.PROGRAM_GLOBAL_ILLUMINATION, W, H, 3, CAM, frame_first=1, frame_count=count, accumulate=True, accumulate_base=0,
+                      tile=plan.desc_tile(r), gi_max_depth=depth)
+        buf = torch.full((plan.floats_per_rank,), -7.0, dtype=torch.float32, device="cuda:0")
+        renderer.render_device(d, buf.data_ptr(), plan.floats_per_rank * 4, stream)
+        torch.cuda.synchronize()
+        stacks.append(buf.cpu().numpy())
+    assert np.array_equal(untile_numpy(plan, stacks), whole)
