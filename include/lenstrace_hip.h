@@ -97,7 +97,10 @@ typedef struct lt_hip_render_desc {
    * the camera buffer's own frameCount, plain overwrite -- exactly Renderer::render().  frame_count > 0:
    * frames with frameCount = frame_first .. frame_first+frame_count-1; with accumulate != 0 they are folded
    * into the output by accumulator.frag's running mean acc = (c + acc*n)/(n+1), n = accumulate_base,
-   * accumulate_base+1, ... (n == 0 replaces); with accumulate == 0 the last frame wins. */
+   * accumulate_base+1, ... (n == 0 replaces); with accumulate == 0 the last frame wins.
+   * An accumulating call renders all its frames in one kernel launch (up to LT_FUSED_BYTES of scratch memory,
+   * default 16 GiB, per launch) and folds them in frame order: same floats as frame_count calls of one frame,
+   * without their per-launch cost -- pass as many frames per call as the application allows. */
   uint32_t frame_first;
   uint32_t frame_count;
   uint32_t accumulate;
