@@ -28,10 +28,9 @@ class TilePlan:
         one image column -- the centre column of an unrotated camera, see DESIGN.md -- on as few GPUs.  The width is
         narrowed in steps of 8 pixels (the wavefront square) until tiles_x is coprime to world."""
         from math import gcd
-        for w in range(tile, 7, -8):
-            if gcd((width + w - 1) // w, world) == 1:
-                return cls(width, height, depth, w, tile, world)
-        return cls(width, height, depth, tile, tile, world)
+        # (where no width makes it coprime -- 640 pixels over 6 ranks -- the widest tile with the smallest common factor)
+        w = min(range(tile, 7, -8), key=lambda w: (gcd((width + w - 1) // w, world), -w))
+        return cls(width, height, depth, w, tile, world)
 
     @property
     def tiles_x(self):

@@ -14,6 +14,28 @@ from lens_trace_amd.dist import TilePlan, gather_to_root, tile_stack_numpy, unti
 from tests.conftest import GOLDEN
 
 
+def test_balanced_plan_spreads_columns_and_rows_over_all_ranks():
+    """TilePlan.balanced: tiles per row coprime to the world size, so that the tiles of any one tile column (and of any one
+    tile row) are dealt to the ranks as evenly as their number allows."""
+    from math import gcd
+    for W, H, world in ((3840, 2160, 8), (3840, 2160, 2), (3840, 2160, 4), (1920, 1080, 8), (1920, 1080, 3), (640, 480, 6), (100, 70, 1)):
+        plan = TilePlan.balanced(W, H, 3, world)
+        assert plan.tile_h == 64 and plan.tile_w % 8 == 0 and 8 <= plan.tile_w <= 64
+        best = min(gcd((W + w - 1) // w, world) for w in range(8, 65, 8))
+        assert gcd(plan.tiles_x, world) == best
+        if best == 1:
+            owner = np.arange(plan.n_tiles).reshape(plan.tiles_y, plan.tiles_x) % world
+            for column in owner.T:
+                counts = np.bincount(column, minlength=world)
+                assert counts.max() - counts.min() <= 1
+            for row in owner:
+                counts = np.bincount(row, minlength=world)
+                assert counts.max() - counts.min() <= 1
+        # and it is still a partition of the image
+        img = np.random.default_rng(1).random((H, W, 3), dtype=np.float32)
+        assert np.array_equal(untile_numpy(plan, [tile_stack_numpy(plan, r, img) for r in range(world)]), img)
+
+
 def test_tile_plan_covers_every_pixel_once():
     for (W, H, tw, th, n) in [(3840, 2160, 64, 64, 8), (200, 120, 64, 64, 3), (100, 70, 100, 16, 2), (17, 5, 8, 8, 4)]:
         plan = TilePlan(W, H, 3, tw, th, n)

@@ -90,6 +90,27 @@ def test_tile_sharding_of_the_4k_frame_reassembles_exactly(renderer, wall):
     assert np.array_equal(image.cpu().numpy(), whole)
 
 
+def test_bench_partition_of_the_16_sample_frame_reassembles_exactly(renderer, wall):
+    """What `bench.py --gpus 8` computes: every rank's balanced-plan share of the 16-sample running mean in one fused launch,
+    gathered and untiled, equals the whole frame rendered on one GPU."""
+    import torch
+    whole = np.empty((H, W, 3), dtype=np.float32)
+    renderer.render(RenderPropertiesHIP(ACC, (W, H, 3), whole, wall, pCamera=wall.camera, frameFirst=1, frameCount=16, accumulate=True))
+    plan = TilePlan.balanced(W, H, 3, 8)
+    assert plan.tiles_x % 2 == 1          # coprime to 8 ranks: every tile column is spread over all of them
+    stream = torch.cuda.current_stream().cuda_stream
+    stack = torch.zeros((8, plan.floats_per_rank), dtype=torch.float32, device="cuda:0")
+    for r in range(8):
+        d = make_desc(C.PROGRAM_ACCUMULATOR, W, H, 3, wall.camera, frame_first=1, frame_count=16, accumulate=True, accumulate_base=0,
+                      tile=plan.desc_tile(r))
+        renderer.render_device(d, stack[r].data_ptr(), plan.floats_per_rank * 4, stream)
+        assert renderer.stats()["kernel_launches"] == 1
+    image = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0")
+    renderer.untile(stack.data_ptr(), plan.floats_per_rank, 8, W, H, 3, plan.tile_w, plan.tile_h, image.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(image.cpu().numpy(), whole)
+
+
 def test_running_mean_of_16_frames_equals_folding_single_frames(renderer, wall):
     got = np.empty((H, W, 3), dtype=np.float32)
     renderer.render(RenderPropertiesHIP(ACC, (W, H, 3), got, wall, pCamera=wall.camera, frameFirst=1, frameCount=16, accumulate=True))
