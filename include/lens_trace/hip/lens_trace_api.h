@@ -37,12 +37,29 @@ enum RenderPlatform { RENDER_PLATFORM_OPENCL, RENDER_PLATFORM_CUDA, RENDER_PLATF
 enum KernelMode { KERNEL_MODE_LINEAR, KERNEL_MODE_TILE };
 enum ThreadOrganizationMode { THREAD_ORGANIZATION_MODE_MAX_FIT, THREAD_ORGANIZATION_MODE_CUSTOM };
 enum AccelerationStructureExplicitType { ACCELERATION_STRUCTURE_TYPE_BVH };
+enum ImageType { IMAGE_TYPE_JPEG };
 
 struct AccelerationStructureExplicitProperties {
   StructureType sType;
   void* pNext;
   AccelerationStructureExplicitType accelerationStructureExplicitType;
   void* pModel;
+};
+
+// ---- image output (include/lens_trace/image_writer.h, structures.h:81-89) --------------------------------
+struct BufferToImageProperties {
+  StructureType sType;
+  void* pNext;
+  void* pBuffer;               // float[W*H*D], values in [0,1]
+  uint64_t bufferSize;
+  uint64_t imageDimensions[3];
+  ImageType imageType;
+  const char* filename;
+};
+
+class ImageWriter {
+ public:
+  static void writeBufferToImage(BufferToImageProperties bufferToImageProperties);   // value*255 -> 8 bits -> quality-100 JPEG
 };
 
 // ---- the plugin interface ------------------------------------------------------------------------------

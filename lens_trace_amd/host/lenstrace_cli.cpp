@@ -8,9 +8,8 @@
 // with "RENDER_PLATFORM_HIP" as the platform (OPENCL / CUDA scene files are accepted too: their kernel_file_path selects the
 // built-in program by basename) and one optional extension object for the device-side progressive loop:
 //   hip { frame_first, frame_count, accumulate, gi_max_depth, device }
-// Output: .pfm (float RGB, bottom-up as the format demands), .ppm (8-bit, value*255 like src/image_writer.cpp:17), .raw (the
-// float buffer as is).  There is no JPEG encoder here (the reference uses stb_image_write): a ".jpg" path is written as
-// ".ppm" next to it, with a note.
+// Output: .jpg (the reference's format: ImageWriter, value*255 narrowed to 8 bits, quality 100; image_writer.cpp holds the
+// encoder), .pfm (float RGB, bottom-up as the format demands), .ppm (8-bit, same narrowing), .raw (the float buffer as is).
 // The JSON reader below is a ~100-line recursive-descent parser written for this file (objects, arrays, strings, numbers,
 // true/false/null).
 #include <math.h>
@@ -178,10 +177,16 @@ bool endsWith(const std::string& s, const char* suffix) {
 }
 
 bool writeImage(std::string path, const float* rgb, uint64_t W, uint64_t H, uint64_t D) {
-  if (endsWith(path, ".jpg") || endsWith(path, ".jpeg")) {
-    const std::string ppm = path.substr(0, path.find_last_of('.')) + ".ppm";
-    printf("note: no JPEG encoder in this build; writing %s instead of %s\n", ppm.c_str(), path.c_str());
-    path = ppm;
+  if (endsWith(path, ".jpg") || endsWith(path, ".jpeg")) {   // the reference's only format (src/main.cpp:30-32)
+    BufferToImageProperties b = {};
+    b.sType = STRUCTURE_TYPE_BUFFER_TO_IMAGE_PROPERTIES;
+    b.pBuffer = (void*)rgb;
+    b.bufferSize = W * H * D * sizeof(float);
+    b.imageDimensions[0] = W; b.imageDimensions[1] = H; b.imageDimensions[2] = D;
+    b.imageType = IMAGE_TYPE_JPEG;
+    b.filename = path.c_str();
+    ImageWriter::writeBufferToImage(b);
+    return true;
   }
   FILE* f = fopen(path.c_str(), "wb");
   if (!f) { printf("ERROR: cannot write %s\n", path.c_str()); return false; }
