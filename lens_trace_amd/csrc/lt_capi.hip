@@ -468,7 +468,7 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   gp.pixels = (uint32_t)pixels;
   const uint64_t vpixels = pixels * fp.fusedFrames;
   LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_giCtl, 0, kGiCtlWords * sizeof(uint32_t), s));
-  const uint32_t resident = (uint32_t)ctx->cu_count * 4u * LT_GI_WAVES;
+  const uint32_t resident = (uint32_t)ctx->cu_count * 4u * LT_GI_STAGE_WAVES;
   const uint32_t gridA = (uint32_t)std::min<uint64_t>((uint64_t)fp.totalSquares * fp.fusedFrames, resident);
   hipLaunchKernelGGL((lt_gi_primary_kernel<CFG>), dim3(gridA), dim3(kBlock), lds, s, sc, fp, gp, queues);
   LT_HIP_CHECK(ctx, hipGetLastError());
@@ -628,10 +628,10 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
     if (orc) return orc;
   }
   // The global-illumination programs run as a wavefront pipeline with path compaction when the scene is big enough for the
-  // traversal to dominate the ~18 launches and the queue traffic per sample (1 M-triangle wall at 4K, 16 bounces: 34 ms
+  // traversal to dominate the ~18 launches and the queue traffic per sample (1 M-triangle wall at 4K, 16 bounces: 31 ms
   // against 52 ms for the one-lane-per-pixel kernel; 42-triangle Cornell box at 1080p: 3.5 ms against 2.7 ms), or when the
-  // launches serve many frames at once and paths are long (Cornell 1080p, 16 frames per call: 1.50 ms against 1.95 ms per
-  // sample at 16 bounces, but 1.12 against 0.82 ms at 4), and never when work is being counted (the counting kernels
+  // launches serve many frames at once and paths are long (Cornell 1080p, 16 frames per call: 1.55 ms against 1.89 ms per
+  // sample at 16 bounces, but 1.12 against 0.78 ms at 4), and never when work is being counted (the counting kernels
   // re-trace like the reference does).  LT_GI_MEGAKERNEL=1 / =0 force one or the other (A/B measurements, tests of both
   // paths on small scenes).
   const char* ge = getenv("LT_GI_MEGAKERNEL");

@@ -53,11 +53,16 @@ __device__ __forceinline__ void render_square(const SceneDev& sc, const FramePar
   }
 }
 
-// Registers: the traversal is latency-bound and wants every wave slot (8 per SIMD = 64 VGPRs); the single-bounce programs fit
-// that with a few spilled values in their shading code; the 16-bounce / 25-sample programs would spill 85-140 values at 8
-// and run best at 5 waves per SIMD (Cornell GI 1080p, 16 bounces: 3.7 / 3.4 / 3.2 / 3.4 / 4.4 ms at 3 / 4 / 5 / 6 / 8).
+// Registers: the traversal wants every wave slot (8 per SIMD = 64 VGPRs); the single-bounce programs fit that with a few
+// spilled values in their shading code; the 16-bounce / 25-sample programs as ONE kernel would spill 85-140 values at 8 and
+// run best at 5 waves per SIMD (Cornell GI 1080p, 16 bounces, 16 frames per launch: 31.5 / 30.2 / 32.8 / 45.7 ms at
+// 4 / 5 / 6 / 8); the stage kernels of the wavefront GI pipeline hold one ray's state and take 8 (1 M-triangle wall, 4K,
+// 16 frames: 498 / 432 / 395 / 363 ms at 4 / 5 / 6 / 8; Cornell 24.0 -> 24.9 ms).
 #ifndef LT_GI_WAVES
 #define LT_GI_WAVES 5
+#endif
+#ifndef LT_GI_STAGE_WAVES
+#define LT_GI_STAGE_WAVES 8
 #endif
 #ifndef LT_ACC_WAVES
 #define LT_ACC_WAVES 8
@@ -191,7 +196,7 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool keep) {
 }
 
 template <class CFG>
-__global__ __launch_bounds__(kBlock, LT_GI_WAVES) void lt_gi_primary_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t* __restrict__ queues) {
+__global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_primary_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t* __restrict__ queues) {
   extern __shared__ int lds_stack[];
   Stack<CFG::kDeep> st;
   st.lds = lds_stack + threadIdx.x;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_WAVES) void lt_gi_primary_kernel(Scen
 }
 
 template <class CFG>
-__global__ __launch_bounds__(kBlock, LT_GI_WAVES) void lt_gi_bounce_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t depth) {
+__global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_bounce_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t depth) {
   extern __shared__ int lds_stack[];
   Stack<CFG::kDeep> st;
   st.lds = lds_stack + threadIdx.x;
