@@ -57,7 +57,8 @@ __device__ __forceinline__ void render_square(const SceneDev& sc, const FramePar
 // spilled values in their shading code; the 16-bounce / 25-sample programs as ONE kernel would spill 85-140 values at 8 and
 // run best at 5 waves per SIMD (Cornell GI 1080p, 16 bounces, 16 frames per launch: 31.5 / 30.2 / 32.8 / 45.7 ms at
 // 4 / 5 / 6 / 8); the stage kernels of the wavefront GI pipeline hold one ray's state and take 8 (1 M-triangle wall, 4K,
-// 16 frames: 498 / 432 / 395 / 363 ms at 4 / 5 / 6 / 8; Cornell 24.0 -> 24.9 ms).
+// 16 frames: 498 / 432 / 395 / 363 ms at 4 / 5 / 6 / 8; Cornell 24.0 -> 24.9 ms).  basic_lighting (one shadow ray, 25 samples
+// per pixel) sides with the single-bounce programs: 8 waves are +9 % (blob) / +13 % (wall) over 5.
 #ifndef LT_GI_WAVES
 #define LT_GI_WAVES 5
 #endif
@@ -67,7 +68,7 @@ __device__ __forceinline__ void render_square(const SceneDev& sc, const FramePar
 #ifndef LT_ACC_WAVES
 #define LT_ACC_WAVES 8
 #endif
-constexpr int waves_per_simd(int program) { return (program == kBasic || program == kAccumulator || program == kCustom) ? LT_ACC_WAVES : LT_GI_WAVES; }
+constexpr int waves_per_simd(int program) { return (program == kGI || program == kGI25) ? LT_GI_WAVES : LT_ACC_WAVES; }
 
 template <int PROGRAM, class CFG>
 __device__ __forceinline__ void render_kernel_body(const SceneDev& sc, const FrameParams& fp, float* __restrict__ out,
