@@ -538,10 +538,10 @@ static int ensure_square_order(lt_hip_context* ctx, const lt_hip_render_desc* d,
     LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_order, n * sizeof(uint32_t)));
     ctx->order_capacity = n;
   }
-  // pageable source: the copy is staged before the call returns, and earlier launches on `s` that read the old order are
-  // ordered before it
-  LT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_order, ord.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-  LT_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  // (rare path: image size, tiling or camera rotation changed)  No launch of an earlier call, on whatever stream, may still
+  // be reading the old order; and `ord` must outlive the copy.
+  LT_HIP_CHECK(ctx, hipDeviceSynchronize());
+  LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_order, ord.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
   ctx->order_key = key;
   ctx->order_natural = false;
   *order = ctx->d_order;
@@ -692,7 +692,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       const uint32_t resident = (uint32_t)ctx->cu_count * 32u;   // every wave slot of the chip, once
       const dim3 grid(persistent ? (uint32_t)std::min<uint64_t>(nblocks * nf, resident) : (uint32_t)nblocks);
       uint32_t* queues = persistent ? ctx->d_queues + (size_t)launchIndex * 8 : nullptr;
-      // LDS stack rows: with the top entry in a register, the rows below it number at most (interior levels - 1)
+      // LDS stack rows: a lane never holds more entries than a node has interior ancestors (= bvh_height, validate_scene)
       uint32_t lds = (uint32_t)std::max(1, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
       if (giWavefront) {
