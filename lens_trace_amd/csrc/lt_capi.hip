@@ -665,15 +665,21 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       if (ctx->d_samples) LT_HIP_CHECK(ctx, hipFree(ctx->d_samples));
       ctx->d_samples = nullptr;
       ctx->d_samples_bytes = 0;
-      LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_samples, chunk * frameBytes));
-      ctx->d_samples_bytes = chunk * frameBytes;
+      // a device that cannot spare the scratch memory gets shorter launches, down to one sample per launch
+      while (chunk > 1 && hipMalloc((void**)&ctx->d_samples, chunk * frameBytes) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->d_samples = nullptr;
+        chunk /= 2;
+      }
+      ctx->d_samples_bytes = chunk > 1 ? chunk * frameBytes : 0;
     }
   }
-  const bool fused = chunk > 1;
   if (giWavefront) {
-    const int erc = ensure_gi_buffers(ctx, giPixels * chunk);
+    int erc;
+    while ((erc = ensure_gi_buffers(ctx, giPixels * chunk)) != LT_OK && chunk > 1) chunk /= 2;   // (frees what it got, retries smaller)
     if (erc) return erc;
   }
+  const bool fused = chunk > 1;
   const bool paddedTiles = d->width % p.tileW != 0 || d->height % p.tileH != 0;
   ctx->mean_pairs = 0;
   LT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, s));
