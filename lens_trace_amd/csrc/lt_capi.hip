@@ -450,11 +450,15 @@ static int ensure_gi_buffers(lt_hip_context* ctx, uint64_t pixels) {
   return LT_OK;
 }
 
-// One sample of a global-illumination program through the wavefront pipeline (lt_kernel.hpp).
+// fp.fusedFrames samples of a global-illumination program through one set of stage launches of the wavefront pipeline
+// (lt_kernel.hpp): frames sample, sample + 1, ... of the single-sample program (blend25Out == nullptr: the resolve stage
+// writes each frame's clamped colour to out + frame * fp.frameStride, or straight to the image when there is one frame), or
+// samples k0 .. k0 + fusedFrames - 1 of ONE frame of the 25-sample variant (blend25Out = the image: the resolve stage
+// writes raw colours to `out`, lt_gi_blend25_kernel blends them in order and finishes the pixel with accumulateN).
 template <class CFG>
 static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& sc, const FrameParams& fp, float* out, uint32_t lds,
-                            uint64_t pixels, uint32_t sample, uint32_t sampleK, uint32_t sampleCount, uint32_t& launches) {
-  // `pixels` = compact output pixels of ONE frame; fp.fusedFrames frames travel through each launch together
+                            uint64_t pixels, uint32_t sample, uint32_t k0, float* blend25Out, int32_t accumulateN, uint32_t& launches) {
+  // `pixels` = compact output pixels of ONE frame
   GiParams gp{};
   for (int k = 0; k < 2; k++) {
     gp.q[k].o = (float4*)ctx->d_gi[4 * k + 0]; gp.q[k].d = (float4*)ctx->d_gi[4 * k + 1];
@@ -464,7 +468,8 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   uint32_t* queues = ctx->d_giCtl;
   gp.counts = ctx->d_giCtl + 8;
   gp.work = ctx->d_giCtl + 8 + (kMaxStack + 2);
-  gp.sample = sample; gp.sampleK = sampleK; gp.sampleCount = sampleCount;
+  gp.sample = sample;
+  gp.raw = blend25Out ? 1u : 0u;
   gp.pixels = (uint32_t)pixels;
   const uint64_t vpixels = pixels * fp.fusedFrames;
   LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_giCtl, 0, kGiCtlWords * sizeof(uint32_t), s));
@@ -481,6 +486,13 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   hipLaunchKernelGGL((lt_gi_resolve_kernel<CFG>), dim3((uint32_t)((vpixels + 255) / 256)), dim3(256), 0, s, fp, gp, out, (uint32_t)vpixels);
   LT_HIP_CHECK(ctx, hipGetLastError());
   launches++;
+  if (blend25Out) {
+    FrameParams fb = fp;
+    fb.accumulateN = accumulateN;
+    hipLaunchKernelGGL((lt_gi_blend25_kernel<CFG>), dim3((uint32_t)((pixels + 255) / 256)), dim3(256), 0, s, fb, gp, out, k0, fp.fusedFrames,
+                       blend25Out, (uint32_t)pixels);
+    LT_HIP_CHECK(ctx, hipGetLastError());
+  }
   return LT_OK;
 }
 
@@ -631,12 +643,14 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   // traversal to dominate the ~18 launches and the queue traffic per sample (1 M-triangle wall at 4K, 16 bounces: 31 ms
   // against 52 ms for the one-lane-per-pixel kernel; 42-triangle Cornell box at 1080p: 3.5 ms against 2.7 ms), or when the
   // launches serve many frames at once and paths are long (Cornell 1080p, 16 frames per call: 1.55 ms against 1.89 ms per
-  // sample at 16 bounces, but 1.12 against 0.78 ms at 4), and never when work is being counted (the counting kernels
+  // sample at 16 bounces, but 1.12 against 0.78 ms at 4; the 25 samples of one frame of the 25-sample variant count as many:
+  // 37 against 55 ms at 16 bounces, 27.5 against 21 ms at 4), and never when work is being counted (the counting kernels
   // re-trace like the reference does).  LT_GI_MEGAKERNEL=1 / =0 force one or the other (A/B measurements, tests of both
   // paths on small scenes).
   const char* ge = getenv("LT_GI_MEGAKERNEL");
   const bool giProgram = d->program == LT_PROGRAM_GLOBAL_ILLUMINATION || d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25;
-  const bool giManyLongPaths = d->program == LT_PROGRAM_GLOBAL_ILLUMINATION && frames > 1 && d->accumulate && fp.giMaxDepth > 8;
+  const bool giManyLongPaths = fp.giMaxDepth > 8 && (d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25 ||
+                                                    (d->program == LT_PROGRAM_GLOBAL_ILLUMINATION && frames > 1 && d->accumulate));
   const bool giWavefront = giProgram && !stats && nblocks > 0 && (ge ? atoi(ge) == 0 : (ctx->n_prims >= 1024u || giManyLongPaths));
   const uint64_t giPixels = (uint64_t)p.tilesInCall * p.tileW * p.tileH;
   if (giWavefront && giPixels > 0xffffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many pixels for the GI path queues");
@@ -650,28 +664,32 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   // The wavefront GI pipeline fuses the same way (single-sample program only: the 25-sample blend is sequential per pixel):
   // its ~18 stage launches then serve all frames of a chunk, each path carrying its frame; its per-frame scratch is the path
   // queues and the direct / indirect images (11 arrays of 16 bytes per pixel) besides the sample image.
+  // The 25-sample variant fuses the samples of ONE frame instead (its frames stay sequential): `chunk` is then the number of
+  // samples k per set of launches, and lt_gi_blend25_kernel replaces the running mean.
   uint32_t chunk = 1;
   const bool giFusable = giWavefront && d->program == LT_PROGRAM_GLOBAL_ILLUMINATION;
-  if ((giFusable || (persistent && !giWavefront)) && !stats && frames > 1 && d->accumulate && nblocks > 0) {
+  const bool gi25Sets = giWavefront && d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25;
+  if (gi25Sets || ((giFusable || (persistent && !giWavefront)) && !stats && frames > 1 && d->accumulate && nblocks > 0)) {
     const char* fe = getenv("LT_FUSED_FRAMES");
     const char* fb = getenv("LT_FUSED_BYTES");
     const uint64_t cap = fb ? strtoull(fb, nullptr, 10) : (16ull << 30);
     const uint64_t frameBytes = p.floats * sizeof(float);
-    const uint64_t scratchPerFrame = frameBytes + (giFusable ? giPixels * 16 * 11 : 0);
+    const uint64_t scratchPerFrame = frameBytes + (giWavefront ? giPixels * 16 * 11 : 0);
     if (!(fe && atoi(fe) == 0) && frameBytes > 0)
-      chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)frames, cap / scratchPerFrame, 0xffffffffull / nblocks,
-                                                                  giFusable ? 0xffffffffull / std::max<uint64_t>(giPixels, 1) : ~0ull}));
-    if (chunk > 1 && ctx->d_samples_bytes < chunk * frameBytes) {
+      chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(gi25Sets ? 25u : frames), cap / scratchPerFrame, 0xffffffffull / nblocks,
+                                                                  giWavefront ? 0xffffffffull / std::max<uint64_t>(giPixels, 1) : ~0ull}));
+    if ((chunk > 1 || gi25Sets) && ctx->d_samples_bytes < chunk * frameBytes) {
       if (ctx->d_samples) LT_HIP_CHECK(ctx, hipFree(ctx->d_samples));
       ctx->d_samples = nullptr;
       ctx->d_samples_bytes = 0;
       // a device that cannot spare the scratch memory gets shorter launches, down to one sample per launch
-      while (chunk > 1 && hipMalloc((void**)&ctx->d_samples, chunk * frameBytes) != hipSuccess) {
+      while ((chunk > 1 || gi25Sets) && hipMalloc((void**)&ctx->d_samples, chunk * frameBytes) != hipSuccess) {
         (void)hipGetLastError();
         ctx->d_samples = nullptr;
+        if (chunk == 1) return fail(ctx, LT_ERR_HIP, "out of device memory for one sample image");
         chunk /= 2;
       }
-      ctx->d_samples_bytes = chunk > 1 ? chunk * frameBytes : 0;
+      ctx->d_samples_bytes = ctx->d_samples ? chunk * frameBytes : 0;
     }
   }
   if (giWavefront) {
@@ -679,6 +697,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
     while ((erc = ensure_gi_buffers(ctx, giPixels * chunk)) != LT_OK && chunk > 1) chunk /= 2;   // (frees what it got, retries smaller)
     if (erc) return erc;
   }
+  const uint32_t samplesPerSet = gi25Sets ? chunk : 0u;   // 25-sample variant: samples k per set of stage launches
+  if (gi25Sets) chunk = 1;                                // ... and its frames stay one per iteration of the loop below
   const bool fused = chunk > 1;
   const bool paddedTiles = d->width % p.tileW != 0 || d->height % p.tileH != 0;
   ctx->mean_pairs = 0;
@@ -702,14 +722,28 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       uint32_t lds = (uint32_t)std::max(1, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
       if (giWavefront) {
-        const uint32_t samples = d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25 ? 25u : 1u;
-        for (uint32_t k = 0; k < samples; k++) {
-          const uint32_t sample = samples > 1 ? fp.frameCount * 32u + k : fp.frameCount;
+        // one set of stage launches for the nf frames of this iteration, or ceil(25 / samplesPerSet) sets for the 25 samples
+        // of its single frame
+        const uint32_t sets = gi25Sets ? (25u + samplesPerSet - 1u) / samplesPerSet : 1u;
+        for (uint32_t set = 0; set < sets; set++) {
+          const uint32_t k0 = set * samplesPerSet;
+          FrameParams fs = fp;
+          float* blendOut = nullptr;
+          float* stageOut = out_launch;
+          uint32_t sample = fp.frameCount;
+          if (gi25Sets) {
+            fs.fusedFrames = std::min(samplesPerSet, 25u - k0);
+            fs.frameStride = p.floats;
+            fs.accumulateN = -1;
+            blendOut = out_device;
+            stageOut = ctx->d_samples;
+            sample = fp.frameCount * 32u + k0;
+          }
           int grc;
-          if (deep) grc = devlibm ? launch_gi_sample<Config<true, false, true>>(ctx, s, sc, fp, out_launch, lds, giPixels, sample, k, samples, launches)
-                                  : launch_gi_sample<Config<true, false, false>>(ctx, s, sc, fp, out_launch, lds, giPixels, sample, k, samples, launches);
-          else grc = devlibm ? launch_gi_sample<Config<false, false, true>>(ctx, s, sc, fp, out_launch, lds, giPixels, sample, k, samples, launches)
-                             : launch_gi_sample<Config<false, false, false>>(ctx, s, sc, fp, out_launch, lds, giPixels, sample, k, samples, launches);
+          if (deep) grc = devlibm ? launch_gi_sample<Config<true, false, true>>(ctx, s, sc, fs, stageOut, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches)
+                                  : launch_gi_sample<Config<true, false, false>>(ctx, s, sc, fs, stageOut, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches);
+          else grc = devlibm ? launch_gi_sample<Config<false, false, true>>(ctx, s, sc, fs, stageOut, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches)
+                             : launch_gi_sample<Config<false, false, false>>(ctx, s, sc, fs, stageOut, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches);
           if (grc) return grc;
         }
         launches--;   // (counted again below)

@@ -161,14 +161,15 @@ struct GiParams {
   GiQueue q[2];            // ping-pong: stage d reads q[d & 1], writes q[(d + 1) & 1]
   float4* direct;          // per pixel (compact output index): direct colour
   float4* indirect;        // per pixel: indirect sum so far
-  float4* blend;           // per pixel: running blend of the 25-sample variant
+  float4* blend;           // per pixel: running blend of the 25-sample variant (between chunks of its samples)
   uint32_t* counts;        // [maxDepth + 1] queue lengths
   uint32_t* work;          // [maxDepth + 1] chunk counters of the bounce launches
   uint32_t sample;         // sampleIndex passed to shade (frameCount, or frameCount*32 + k) of the launch's first frame
-  uint32_t sampleK;        // k of the 25-sample loop (0 for the single-sample program)
-  uint32_t sampleCount;    // 25 or 1
-  // Several frames per set of launches (single-sample program only; FrameParams::fusedFrames of them): frame f uses sample
-  // + f, its pixels live at [f * pixels, (f + 1) * pixels) of direct / indirect, and every path carries its frame (m.w).
+  uint32_t raw;            // != 0: the resolve stage stores direct + indirect as is (25-sample variant: lt_gi_blend25_kernel
+                           // blends, clamps and accumulates afterwards); 0: it clamps (the frame's own colour is final)
+  // Several frames per set of launches (FrameParams::fusedFrames of them; for the 25-sample variant the "frames" are the
+  // samples k of one frame): frame f uses sample + f, its pixels live at [f * pixels, (f + 1) * pixels) of direct / indirect,
+  // and every path carries its frame (m.w).
   uint32_t pixels;         // compact output pixels of one frame
 };
 
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_bounce_kernel
   }
 }
 
-// direct + indirect (gi.cl:374), the 25-sample blend (resources gi :408-415), clamp (:409-411), running mean, store
+// direct + indirect (gi.cl:374), clamp (:409-411), running mean, store
 template <class CFG>
 __global__ void lt_gi_resolve_kernel(FrameParams fp, GiParams gp, float* __restrict__ out, uint32_t pixels) {
   const uint32_t vpix = blockIdx.x * blockDim.x + threadIdx.x;   // (frame, pixel) of a fused launch
@@ -336,18 +337,7 @@ __global__ void lt_gi_resolve_kernel(FrameParams fp, GiParams gp, float* __restr
   if (k >= fp.tilesInCall || tx * fp.tileW + lx >= fp.width || ty * fp.tileH + ly >= fp.height) return;
   const float4 di = gp.direct[vpix], in = gp.indirect[vpix];
   V3 color{di.x + in.x, di.y + in.y, di.z + in.z};
-  if (gp.sampleCount > 1u) {
-    if (gp.sampleK > 0u) {
-      const float4 b = gp.blend[pix];
-      const float a = ((float)(25 - (int)gp.sampleK)) / (float)25;
-      color = V3{((1.0f - a) * b.x) + (a * color.x), ((1.0f - a) * b.y) + (a * color.y), ((1.0f - a) * b.z) + (a * color.z)};
-    }
-    if (gp.sampleK + 1u < gp.sampleCount) {
-      gp.blend[pix] = make_float4(color.x, color.y, color.z, 0.0f);
-      return;
-    }
-  }
-  if (fp.clampOutput) color = V3{Math<CFG::kDevLibm>::clamp01(color.x), Math<CFG::kDevLibm>::clamp01(color.y), Math<CFG::kDevLibm>::clamp01(color.z)};
+  if (fp.clampOutput && !gp.raw) color = V3{Math<CFG::kDevLibm>::clamp01(color.x), Math<CFG::kDevLibm>::clamp01(color.y), Math<CFG::kDevLibm>::clamp01(color.z)};
   float* o = out + (size_t)frame * fp.frameStride + (size_t)pix * fp.depth;   // fused: this frame's un-accumulated slice
   if (fp.accumulateN <= 0) {
     o[0] = color.x; o[1] = color.y; o[2] = color.z;
@@ -356,5 +346,49 @@ __global__ void lt_gi_resolve_kernel(FrameParams fp, GiParams gp, float* __restr
     o[0] = (color.x + (o[0] * n)) / n1;
     o[1] = (color.y + (o[1] * n)) / n1;
     o[2] = (color.z + (o[2] * n)) / n1;
+  }
+}
+
+// The 25-sample variant (resources/kernels/opencl/global_illumination.cl:408-420): samples k0 .. k0+n-1 of one frame, stored
+// un-clamped by the resolve stage at samples + j * stride, are blended in order, `c = (1-a)*c + a*c_k`, a = (25-k)/25; the
+// partial blend waits in gp.blend between chunks; after sample 24 the colour is clamped (linearKernel) and stored or folded
+// into the running mean like any frame.  Pixels of edge tiles outside the image are skipped.
+template <class CFG>
+__global__ void lt_gi_blend25_kernel(FrameParams fp, GiParams gp, const float* __restrict__ samples, uint32_t k0, uint32_t n,
+                                     float* __restrict__ out, uint32_t pixels) {
+  const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= pixels) return;
+  const uint32_t perTile = fp.tileW * fp.tileH, k = pix / perTile, rem = pix % perTile, ly = rem / fp.tileW, lx = rem % fp.tileW;
+  const uint32_t tile = fp.tileFirst + k * fp.tileStride, tx = tile % fp.tilesX, ty = tile / fp.tilesX;
+  if (k >= fp.tilesInCall || tx * fp.tileW + lx >= fp.width || ty * fp.tileH + ly >= fp.height) return;
+  V3 color{0.0f, 0.0f, 0.0f};
+  if (k0 > 0u) {
+    const float4 b = gp.blend[pix];
+    color = V3{b.x, b.y, b.z};
+  }
+  for (uint32_t j = 0; j < n; j++) {
+    const float* c = samples + (size_t)j * fp.frameStride + (size_t)pix * fp.depth;
+    const V3 cn{c[0], c[1], c[2]};
+    const uint32_t kk = k0 + j;
+    if (kk == 0u) {
+      color = cn;
+    } else {
+      const float a = ((float)(25 - (int)kk)) / (float)25;
+      color = V3{((1.0f - a) * color.x) + (a * cn.x), ((1.0f - a) * color.y) + (a * cn.y), ((1.0f - a) * color.z) + (a * cn.z)};
+    }
+  }
+  if (k0 + n < 25u) {
+    gp.blend[pix] = make_float4(color.x, color.y, color.z, 0.0f);
+    return;
+  }
+  if (fp.clampOutput) color = V3{Math<CFG::kDevLibm>::clamp01(color.x), Math<CFG::kDevLibm>::clamp01(color.y), Math<CFG::kDevLibm>::clamp01(color.z)};
+  float* o = out + (size_t)pix * fp.depth;
+  if (fp.accumulateN <= 0) {
+    o[0] = color.x; o[1] = color.y; o[2] = color.z;
+  } else {
+    const float nf = (float)fp.accumulateN, n1 = (float)(fp.accumulateN + 1);
+    o[0] = (color.x + (o[0] * nf)) / n1;
+    o[1] = (color.y + (o[1] * nf)) / n1;
+    o[2] = (color.z + (o[2] * nf)) / n1;
   }
 }

@@ -172,3 +172,34 @@ def test_wavefront_gi_fused_chunks_and_tiles(renderer, cornell, monkeypatch):
         torch.cuda.synchronize()
         stacks.append(buf.cpu().numpy())
     assert np.array_equal(untile_numpy(plan, stacks), whole)
+
+
+# ---- the 25-sample variant: the samples of one frame through as few sets of stage launches as the scratch cap allows ----
+def test_wavefront_gi25_sample_sets(renderer, cornell, monkeypatch):
+    GI25 = "resources/kernels/opencl/global_illumination.cl"
+    W, H, depth = 72, 40, 3
+    cam = sc.camera_bytes(0.0, 2.5, -50.0, 0.0, 0.0, 0.0, 2)
+    want = po.render(cornell, cam, W, H, po.GI25, gi_max_depth=depth)
+    monkeypatch.setenv("LT_GI_MEGAKERNEL", "0")
+
+    def once(**kw):
+        out = np.full((H, W, 3), np.nan, dtype=np.float32)
+        renderer.render(RenderPropertiesHIP(GI25, (W, H, 3), out, cornell, pCamera=cam, giMaxDepth=depth, **kw))
+        return out, renderer.stats()["kernel_launches"]
+
+    got, launches = once()
+    assert launches == depth + 2                       # all 25 samples in one set of launches
+    assert np.array_equal(got, want)
+    per_sample = W * H * (3 * 4 + 16 * 11)
+    monkeypatch.setenv("LT_FUSED_BYTES", str(7 * per_sample + 8))      # 7 + 7 + 7 + 4 samples per set
+    got, launches = once()
+    assert launches == 4 * (depth + 2)
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("LT_FUSED_BYTES", "1")                          # one sample per set
+    got, launches = once()
+    assert launches == 25 * (depth + 2)
+    assert np.array_equal(got, want)
+    monkeypatch.delenv("LT_FUSED_BYTES")
+    monkeypatch.setenv("LT_GI_MEGAKERNEL", "1")
+    got, launches = once()
+    assert launches == 1 and np.array_equal(got, want)

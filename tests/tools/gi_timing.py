@@ -12,6 +12,8 @@ from lens_trace_amd import scene as sc, synth  # noqa: E402
 from lens_trace_amd.renderer import RendererHIP, RenderPropertiesHIP  # noqa: E402
 
 GI = "examples/global_illumination/resources/kernels/global_illumination.cl"
+if os.environ.get("LT_GI25") == "1":   # the 25-sample variant (the reference CLI's global_illumination.scene)
+    GI = "resources/kernels/opencl/global_illumination.cl"
 FRAMES = int(os.environ.get("LT_FRAMES", "1"))   # > 1: a running mean of that many frames per call (ms printed per call)
 r = RendererHIP(0)
 for name, scene, W, H in (("cornell", sc.load_ltsb(os.path.join(ROOT, "tests", "golden", "cornell_box_O0.ltsb")), 1920, 1080),
