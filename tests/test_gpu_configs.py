@@ -51,6 +51,17 @@ def test_config2_cornell_global_illumination_1080p(renderer):
         assert got.min() >= 0.0 and got.max() <= 1.0
     # 35 % of the frame shows the box, the rest misses (primitive 0 is not a light here)
     assert 0.2 < (got.sum(axis=2) > 0).mean() < 0.6
+    # 16 frames per call (the wavefront pipeline carries all of them through one set of stage launches at 16 bounces, the
+    # single kernel renders them in one launch at 4) == folding 16 single-frame calls with accumulator.frag's formula
+    for depth in (16, 4):
+        many, _ = render(renderer, s, GI, W, H, frameFirst=1, frameCount=16, accumulate=True, giMaxDepth=depth)
+        st = renderer.stats()
+        print("config 2: depth %d, 16 frames per call: %.2f ms kernel per frame, %d launches" % (depth, st["kernel_ms"] / 16, st["kernel_launches"]))
+        acc = np.zeros((H, W, 3), dtype=np.float32)
+        for i, f in enumerate(range(1, 17)):
+            frame, _ = render(renderer, s, GI, W, H, frame=f, giMaxDepth=depth)
+            po.accumulate(acc.reshape(-1), frame.reshape(-1), i)
+        assert np.array_equal(many, acc)
 
 
 def test_config3_blob_accumulator_1080p_64_frames(renderer):
