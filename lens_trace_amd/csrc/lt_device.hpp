@@ -352,7 +352,9 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
 //    reference traversal; the wave descends while any lane hits;
 //  * no per-lane stack, no divergence inside the walk; the triangle test runs for the lanes that hit the leaf's box.
 typedef float F4v __attribute__((ext_vector_type(4)));
+typedef float F8v __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) F4v* ConstF4;   // constant address space: uniform loads become s_load
+typedef const __attribute__((address_space(4))) F8v* ConstF8;
 __device__ __forceinline__ float4 ld_const(ConstF4 p) { const F4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 
 template <int PROGRAM, bool STATS>
@@ -367,7 +369,10 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
   int cur = 0, sp = 0;
   for (;;) {
     const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane(cur);
-    const float4 a = ld_const(nodes + 2 * (size_t)ci), b = ld_const(nodes + 2 * (size_t)ci + 1);
+    // the whole 32-byte record in ONE s_load_dwordx8 (as two dwordx4 the compiler sinks the first half into the `in`
+    // branch below and the two scalar-load latencies add up)
+    const F8v nd = *(ConstF8)(nodes + 2 * (size_t)ci);
+    const float4 a = make_float4(nd.s0, nd.s1, nd.s2, nd.s3), b = make_float4(nd.s4, nd.s5, nd.s6, nd.s7);
     const bool in = (mask >> lane) & 1ull;
     if (STATS && in) c.nodes++;
 #ifdef LT_DEBUG_WAVE_COUNTERS
