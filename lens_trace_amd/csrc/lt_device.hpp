@@ -366,6 +366,7 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
   const int lane = (int)__lane_id();
   u64 mask = __ballot(1);
   const int leader = __ffsll((long long)mask) - 1;
+  const uint32_t negBitsU = (nxU ? 1u : 0u) | (nyU ? 2u : 0u) | (nzU ? 4u : 0u);
   int cur = 0, sp = 0;
   for (;;) {
     const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane(cur);
@@ -373,20 +374,19 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
     // branch below and the two scalar-load latencies add up)
     const F8v nd = *(ConstF8)(nodes + 2 * (size_t)ci);
     const float4 a = make_float4(nd.s0, nd.s1, nd.s2, nd.s3), b = make_float4(nd.s4, nd.s5, nd.s6, nd.s7);
-    const bool in = (mask >> lane) & 1ull;
-    if (STATS && in) c.nodes++;
+    if (STATS && ((mask >> lane) & 1ull)) c.nodes++;
 #ifdef LT_DEBUG_WAVE_COUNTERS
     if (lane == 0) c.wInner++;
-    if (in) c.wOuter++;
+    if ((mask >> lane) & 1ull) c.wOuter++;
 #endif
-    const bool hit = in && box_test_finite(a.x, a.y, a.z, a.w, b.x, b.y, ray, ix, iy, iz);
-    const u64 hmask = __ballot(hit);
+    // every active lane runs the slab test (the wave pays for it anyway); masking the ballot with the wave-uniform `mask`
+    // instead of branching on the lane's bit keeps the control flow scalar
+    const u64 hmask = __builtin_amdgcn_ballot_w64(box_test_finite(a.x, a.y, a.z, a.w, b.x, b.y, ray, ix, iy, iz)) & mask;
     const uint32_t meta = __float_as_uint(b.w);
     const int off = __float_as_int(b.z);
     const uint32_t count = meta & 0xffffu;
     if (hmask != 0ull && count == 0u) {
-      const uint32_t axis = (meta >> 16) & 0xffu;
-      const bool neg = axis == 0 ? nxU : (axis == 1 ? nyU : nzU);
+      const bool neg = (negBitsU >> ((meta >> 16) & 0xffu)) & 1u;   // dirIsNeg[axis], shared by the wave
       const int farChild = neg ? (int)ci + 1 : off;
       if (lane == leader) {   // any lane may be switched off (image edge): the first active one writes the entry
         ldsWave[sp * kBlock + 0] = farChild;
@@ -402,7 +402,7 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
 #ifdef LT_DEBUG_WAVE_COUNTERS
       if (lane == 0) c.wTri++;
 #endif
-      if (hit) {
+      if ((hmask >> lane) & 1ull) {
         if (STATS) c.tris += count;    // the reference *calls* intersectTriangle primitiveCount times
         const ConstF4 t = tris + 3 * (size_t)(uint32_t)off;
         const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
@@ -428,7 +428,8 @@ __device__ inline void traverse_camera(const SceneDev& sc, const Ray& ray, Hit& 
                       __builtin_fabsf(iz) < __builtin_inff() && __builtin_fabsf(ray.o.x) < __builtin_inff() &&
                       __builtin_fabsf(ray.o.y) < __builtin_inff() && __builtin_fabsf(ray.o.z) < __builtin_inff();
   const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
-  const unsigned long long all = __ballot(1), bx = __ballot(nx), by = __ballot(ny), bz = __ballot(nz);
+  const unsigned long long all = __builtin_amdgcn_ballot_w64(true), bx = __builtin_amdgcn_ballot_w64(nx), by = __builtin_amdgcn_ballot_w64(ny),
+                           bz = __builtin_amdgcn_ballot_w64(nz);   // (the builtin takes the bool as is; __ballot(int) re-materialises it)
   const bool uniformSigns = (bx == 0ull || bx == all) && (by == 0ull || by == all) && (bz == 0ull || bz == all);
 #ifndef LT_NO_PACKETS
   constexpr bool kPackets = !DEEP;   // the wave-uniform stack shares the LDS rows, which cover BVH heights <= kLdsStack
