@@ -263,9 +263,13 @@ __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float 
 //    right behind the issue of the next node's loads, so both latencies overlap (testing it inside iteration i costs 25 %).
 //    Exact: the reference's traversal never reads the payload (no clipping against payload.t, acc.cl:113-130), and a lane
 //    still tests its leaves in reference order;
-//  * the stack is plain: push and pop go to the lane's LDS column.  (Under one launch per sample, where the chain per node
-//    mattered more than the instruction count, keeping the top entry in a register and batching the triangle tests until
-//    16 lanes held one were each worth a few per cent; with fused launches they cost 5 % and 2-6 %.)
+//  * the stack is plain -- push and pop go to the lane's LDS column -- and the step has no branch: every lane reads the entry
+//    below its top and stores once (interior lanes the far child above the top, the others the value they just read, back
+//    where it was), selects decide what counts: +2 % over an if / else.  (Storing above the top unconditionally is another
+//    +0.6 %, but a lane at a deepest leaf would write one row past the launch's LDS stack.)
+//    (Under one launch per sample, where the chain per node mattered more than the instruction count, keeping the top entry
+//    in a register and batching the triangle tests until 16 lanes held one were each worth a few per cent; with fused
+//    launches they cost 5 % and 2-6 %.)
 // ANYHIT (shadow rays, only when not counting work): the callers of a shadow ray read nothing but `hitType == 0`
 // (acc.cl:276, gi.cl:295,:351), so the walk may stop at the first accepted triangle -- same pixels, fewer node visits
 // than the reference algorithm performs.  The counting (STATS) instantiations never use it.
@@ -301,22 +305,20 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
       }
       pend = -1;
     }
-    if (hit && count == 0) {
+    {   // branch-free step: selects instead of an interior / leaf-or-miss branch (fewer scalar instructions, no exec juggling)
+      const bool inner = hit && count == 0;
       const bool neg = (negBits >> ((meta >> 16) & 0xffu)) & 1u;
-      st.push(sp, neg ? cur + 1 : off);
-      sp++;
-      cur = neg ? off : cur + 1;
-    } else {
-      if (newLeaf) {
-        pend = off;
-        pendCount = count;
-      }
-      if (sp == 0) {
-        alive = false;
-      } else {
-        sp--;
-        cur = st.pop(sp);
-      }
+      const int left = cur + 1;
+      const int below = sp > 0 ? sp - 1 : 0;               // (row 0, unused, for a lane that is about to end)
+      const int popped = st.pop(below);
+      // one unconditional store: interior lanes push the far child; the others rewrite the entry they just read (a lane at
+      // a deepest leaf has no row `sp` to scribble on)
+      st.push(inner ? sp : below, inner ? (neg ? left : off) : popped);
+      pend = newLeaf ? off : pend;
+      if (STATS) pendCount = newLeaf ? count : pendCount;
+      alive = inner || sp > 0;
+      cur = inner ? (neg ? off : left) : popped;
+      sp += inner ? 1 : -1;
     }
   }
   if (pend >= 0) {
