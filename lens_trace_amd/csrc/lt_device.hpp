@@ -288,6 +288,9 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
     // 64-bit address arithmetic on the node-to-node dependency chain (n_nodes * 32 < 2^32 is checked at set_scene)
     const float4* n = (const float4*)((const char*)sc.nodes + ((uint32_t)cur << 5));
     const float4 a = n[0], b = n[1];   // a = min.x min.y min.z max.x ; b = max.y max.z offset count|axis<<16
+    // the entry below the top is read now, beside the node fetch, whether or not this node turns out to need it
+    const int below = sp > 0 ? sp - 1 : 0;               // (row 0, unused, for a lane that is about to end)
+    const int popped = st.pop(below);
     if (STATS) c.nodes++;
     LT_WAVE_COUNT(wInner);
     const bool hit = box_test<FINITE>(a.x, a.y, a.z, a.w, b.x, b.y, ray, ix, iy, iz, nx, ny, nz);
@@ -309,8 +312,6 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
       const bool inner = hit && count == 0;
       const bool neg = (negBits >> ((meta >> 16) & 0xffu)) & 1u;
       const int left = cur + 1;
-      const int below = sp > 0 ? sp - 1 : 0;               // (row 0, unused, for a lane that is about to end)
-      const int popped = st.pop(below);
       // one unconditional store: interior lanes push the far child; the others rewrite the entry they just read (a lane at
       // a deepest leaf has no row `sp` to scribble on)
       st.push(inner ? sp : below, inner ? (neg ? left : off) : popped);
