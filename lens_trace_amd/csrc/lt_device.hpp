@@ -198,6 +198,9 @@ __device__ __forceinline__ bool intersect_triangle(const float4* __restrict__ tr
 // The per-lane traversal stack: entries [0,kLdsStack) live in LDS (column `lane`, row stride kBlock, so
 // every wave access is one conflict-free row), deeper entries (only for BVHs deeper than kLdsStack, chosen
 // by the host from the scene's measured height) in a per-lane scratch array.
+template <bool B, class T, class F> struct SelectType { using type = T; };
+template <class T, class F> struct SelectType<false, T, F> { using type = F; };
+
 template <bool DEEP>
 struct Stack {
   int* lds;            // &lds_stack[threadIdx.x]
@@ -209,6 +212,15 @@ struct Stack {
     if (!DEEP || sp < kLdsStack) return lds[sp * kBlock];
     return deep[sp - kLdsStack];
   }
+  // A stack position as the loop variable of the per-lane walk: the LDS row pointer itself when the whole stack is in LDS
+  // (stepping it by a row is one add; an index would cost a shift-add per access), the entry index otherwise.
+  using Pos = typename SelectType<DEEP, int, int*>::type;
+  __device__ __forceinline__ Pos bottom() { if constexpr (DEEP) return 0; else return lds; }
+  __device__ __forceinline__ bool above_bottom(Pos p) { if constexpr (DEEP) return p > 0; else return p > lds; }
+  __device__ __forceinline__ Pos below(Pos p) { if constexpr (DEEP) return p > 0 ? p - 1 : 0; else return p > lds ? p - kBlock : lds; }
+  __device__ __forceinline__ Pos step(Pos p, bool up) { if constexpr (DEEP) return p + (up ? 1 : -1); else return p + (up ? kBlock : -kBlock); }
+  __device__ __forceinline__ int load(Pos p) { if constexpr (DEEP) return pop(p); else return *p; }
+  __device__ __forceinline__ void store(Pos p, int v) { if constexpr (DEEP) push(p, v); else *p = v; }
 };
 
 // acc.cl:132-171 (intersect) and :173-217 (intersectIgnorePrimitiveIndex): same node order (near child
@@ -279,7 +291,8 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
   const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
   const uint32_t negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);   // dirIsNeg[axis] = bit `axis` (axis <= 2: set_scene)
   const int ign = useIgnore ? ignore : -1;   // leaf offsets are >= 0
-  int cur = 0, sp = 0;
+  int cur = 0;
+  typename Stack<DEEP>::Pos sp = st.bottom();   // where the next entry goes
   int pend = -1;
   uint32_t pendCount = 0;
   bool alive = true;
@@ -289,8 +302,8 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
     const float4* n = (const float4*)((const char*)sc.nodes + ((uint32_t)cur << 5));
     const float4 a = n[0], b = n[1];   // a = min.x min.y min.z max.x ; b = max.y max.z offset count|axis<<16
     // the entry below the top is read now, beside the node fetch, whether or not this node turns out to need it
-    const int below = sp > 0 ? sp - 1 : 0;               // (row 0, unused, for a lane that is about to end)
-    const int popped = st.pop(below);
+    const typename Stack<DEEP>::Pos below = st.below(sp);   // (the bottom row, unused, for a lane that is about to end)
+    const int popped = st.load(below);
     if (STATS) c.nodes++;
     LT_WAVE_COUNT(wInner);
     const bool hit = box_test<FINITE>(a.x, a.y, a.z, a.w, b.x, b.y, ray, ix, iy, iz, nx, ny, nz);
@@ -314,12 +327,12 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
       const int left = cur + 1;
       // one unconditional store: interior lanes push the far child; the others rewrite the entry they just read (a lane at
       // a deepest leaf has no row `sp` to scribble on)
-      st.push(inner ? sp : below, inner ? (neg ? left : off) : popped);
+      st.store(inner ? sp : below, inner ? (neg ? left : off) : popped);
       pend = newLeaf ? off : pend;
       if (STATS) pendCount = newLeaf ? count : pendCount;
-      alive = inner || sp > 0;
+      alive = inner || st.above_bottom(sp);
       cur = inner ? (neg ? off : left) : popped;
-      sp += inner ? 1 : -1;
+      sp = st.step(sp, inner);
     }
   }
   if (pend >= 0) {
