@@ -28,6 +28,24 @@ __global__ void lt_retile_kernel(const float* __restrict__ prims, float4* __rest
   tris[3 * (size_t)i + 2] = make_float4(p[8] - az, 0.0f, 0.0f, 0.0f);
 }
 
+// Child-pair records for the packet walk (traverse_packet_pairs): pairs[i] = (record of node i + 1, record of node
+// secondChildOffset(i)) for every interior node i, an interior child's `offset` field replaced by that child's own index.
+// Leaves get no record (their slot stays unwritten and is never read).
+__global__ void lt_pair_kernel(const float4* __restrict__ nodes, float4* __restrict__ pairs, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 b = nodes[2 * (size_t)i + 1];
+  if ((__float_as_uint(b.w) & 0xffffu) != 0u) return;
+  const uint32_t child[2] = {i + 1u, __float_as_uint(b.z)};
+  for (int k = 0; k < 2; k++) {
+    const float4 ca = nodes[2 * (size_t)child[k]];
+    float4 cb = nodes[2 * (size_t)child[k] + 1];
+    if ((__float_as_uint(cb.w) & 0xffffu) == 0u) cb.z = __uint_as_float(child[k]);
+    pairs[4 * (size_t)i + 2 * k] = ca;
+    pairs[4 * (size_t)i + 2 * k + 1] = cb;
+  }
+}
+
 // Gathered per-rank tile stacks -> row-major image (root side of the one gather per frame).
 __global__ void lt_untile_kernel(const float* __restrict__ gathered, uint64_t floatsPerRank, uint32_t nRanks, uint32_t W,
                                  uint32_t H, uint32_t depth, uint32_t tileW, uint32_t tileH, uint32_t tilesX,
@@ -76,7 +94,7 @@ struct lt_hip_context {
   int device = -1;
   std::string err;
   hipStream_t stream = nullptr;      // own stream for lt_hip_render
-  void *d_nodes = nullptr, *d_tris = nullptr, *d_prims = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+  void *d_nodes = nullptr, *d_pairs = nullptr, *d_tris = nullptr, *d_prims = nullptr, *d_mats = nullptr, *d_lights = nullptr;
   uint32_t n_nodes = 0, n_prims = 0, n_mats = 0;
   int bvh_height = 0;
   bool has_scene = false;
@@ -159,7 +177,7 @@ extern "C" int lt_hip_create(int device_index, lt_hip_context** out_ctx) {
 }
 
 static void free_scene(lt_hip_context* ctx) {
-  for (void** p : {&ctx->d_nodes, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights}) {
+  for (void** p : {&ctx->d_nodes, &ctx->d_pairs, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -377,6 +395,11 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
   hipLaunchKernelGGL(lt_retile_kernel, dim3((n_prims + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->d_prims,
                      (float4*)ctx->d_tris, n_prims);
   LT_HIP_CHECK(ctx, hipGetLastError());
+  if (n_nodes > 0x1fffffffu) return fail(ctx, LT_ERR_BAD_SCENE, "too many nodes for the child-pair records");
+  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pairs, (size_t)n_nodes * 64));
+  hipLaunchKernelGGL(lt_pair_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes,
+                     (float4*)ctx->d_pairs, n_nodes);
+  LT_HIP_CHECK(ctx, hipGetLastError());
   LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->n_nodes = n_nodes;
   ctx->n_prims = n_prims;
@@ -587,6 +610,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
 
   SceneDev sc;
   sc.nodes = (const float4*)ctx->d_nodes;
+  sc.pairs = (const float4*)ctx->d_pairs;
   sc.tris = (const float4*)ctx->d_tris;
   sc.prims = (const float*)ctx->d_prims;
   sc.mats = (const Material*)ctx->d_mats;

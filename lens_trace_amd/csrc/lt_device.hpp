@@ -49,6 +49,7 @@ struct Lights { uint32_t count; uint32_t primitives[64]; };                     
 //   prims : the reference's 76-byte Primitive array, verbatim (shading reads positions+normals+material).
 struct SceneDev {
   const float4* nodes;
+  const float4* pairs;      // per interior node index: the records of its two children side by side (64 B; lt_pair_kernel)
   const float4* tris;
   const float* prims;       // 19 floats per primitive
   const Material* mats;
@@ -371,6 +372,8 @@ typedef float F4v __attribute__((ext_vector_type(4)));
 typedef float F8v __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) F4v* ConstF4;   // constant address space: uniform loads become s_load
 typedef const __attribute__((address_space(4))) F8v* ConstF8;
+typedef float F16v __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) F16v* ConstF16;
 __device__ __forceinline__ float4 ld_const(ConstF4 p) { const F4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 
 template <int PROGRAM, bool STATS>
@@ -436,6 +439,100 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
   }
 }
 
+// The packet walk over child-pair records: sc.pairs[i] holds the records of interior node i's two children side by side
+// (left = i + 1, right = secondChildOffset), an interior child's `offset` field replaced by that child's own index, so one
+// 64-byte scalar load serves two slab tests and the walk makes half the dependent fetches.  Order per lane is the
+// reference's: the near child's subtree (or leaf) completely before the far child's; a far child that must wait goes on
+// the wave-uniform stack with the mask of the lanes that hit it (a leaf as 0x80000000 | primitive offset).
+template <int PROGRAM>
+__device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool nxU, bool nyU,
+                                             bool nzU, Hit& pl, int* ldsWave) {
+  using u64 = unsigned long long;
+  constexpr uint32_t kLeafTag = 0x80000000u;
+  const ConstF4 nodes = (ConstF4)(unsigned long long)sc.nodes;
+  const ConstF4 pairs = (ConstF4)(unsigned long long)sc.pairs;
+  const ConstF4 tris = (ConstF4)(unsigned long long)sc.tris;
+  const int lane = (int)__lane_id();
+  const u64 all = __builtin_amdgcn_ballot_w64(true);
+  const int leader = __ffsll((long long)all) - 1;
+  const uint32_t negBitsU = (nxU ? 1u : 0u) | (nyU ? 2u : 0u) | (nzU ? 4u : 0u);
+  auto leaf_test = [&](uint32_t off, u64 m) {
+    if ((m >> lane) & 1ull) {
+      const ConstF4 t = tris + 3 * (size_t)off;
+      const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
+      if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl)) {
+        pl.prim = (int)off;
+        pl.hitType = 1;
+      }
+    }
+  };
+  u64 mask;
+  uint32_t cur;   // interior node: index | axis << 29
+  {
+    const F8v nd = *(ConstF8)(nodes);
+    mask = __builtin_amdgcn_ballot_w64(box_test_finite(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz));
+    if (mask == 0ull) return;
+    const uint32_t meta = __float_as_uint(nd.s7);
+    if ((meta & 0xffffu) != 0u) { leaf_test(__float_as_uint(nd.s6), mask); return; }
+    cur = ((meta >> 16) & 3u) << 29;
+  }
+  int sp = 0;
+  for (;;) {
+    const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));
+    const uint32_t axis = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur >> 29));
+    const F16v pr = *(ConstF16)(pairs + 4 * (size_t)ci);
+    const u64 hmL = __builtin_amdgcn_ballot_w64(box_test_finite(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz)) & mask;
+    const u64 hmR = __builtin_amdgcn_ballot_w64(box_test_finite(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz)) & mask;
+    const bool neg = (negBitsU >> axis) & 1u;
+    const u64 hmN = neg ? hmR : hmL, hmF = neg ? hmL : hmR;
+    const uint32_t refN = __float_as_uint(neg ? pr.se : pr.s6), refF = __float_as_uint(neg ? pr.s6 : pr.se);
+    const uint32_t metaN = __float_as_uint(neg ? pr.sf : pr.s7), metaF = __float_as_uint(neg ? pr.s7 : pr.sf);
+    const bool leafN = (metaN & 0xffffu) != 0u, leafF = (metaF & 0xffffu) != 0u;
+    const uint32_t entF = leafF ? (kLeafTag | refF) : (refF | (((metaF >> 16) & 3u) << 29));
+    bool haveNext = false;
+    if (hmN != 0ull) {
+      if (leafN) {
+        leaf_test(refN, hmN);
+      } else {
+        if (hmF != 0ull) {   // the far child waits for the near subtree
+          if (lane == leader) {
+            ldsWave[sp * kBlock + 0] = (int)entF;
+            ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmF;
+            ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmF >> 32);
+          }
+          sp++;
+        }
+        cur = refN | (((metaN >> 16) & 3u) << 29);
+        mask = hmN;
+        continue;
+      }
+    }
+    if (hmF != 0ull) {   // (the near child was missed, or was a leaf and is done)
+      if (leafF) {
+        leaf_test(refF, hmF);
+      } else {
+        cur = entF;
+        mask = hmF;
+        haveNext = true;
+      }
+    }
+    while (!haveNext) {
+      if (sp == 0) return;
+      sp--;
+      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 0]);
+      const u64 m = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 1]) |
+                    ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 2]) << 32);
+      if (e & kLeafTag) {
+        leaf_test(e & 0x7fffffffu, m);
+      } else {
+        cur = e;
+        mask = m;
+        haveNext = true;
+      }
+    }
+  }
+}
+
 // Camera rays: packet traversal when the wave qualifies, the per-lane traversal otherwise.
 template <int PROGRAM, bool DEEP, bool STATS>
 __device__ inline void traverse_camera(const SceneDev& sc, const Ray& ray, Hit& pl, Stack<DEEP>& st, Counters& c) {
@@ -454,7 +551,10 @@ __device__ inline void traverse_camera(const SceneDev& sc, const Ray& ray, Hit& 
 #endif
   if (kPackets && __all(finite) && uniformSigns) {
     if (STATS) c.rays++;
-    traverse_packet<PROGRAM, STATS>(sc, ray, ix, iy, iz, bx != 0ull, by != 0ull, bz != 0ull, pl, st.lds - __lane_id(), c);
+    // two nodes per iteration from the child-pair records; the counting kernels keep the one-node walk, whose stack entries
+    // need no leaf counts
+    if (STATS) traverse_packet<PROGRAM, STATS>(sc, ray, ix, iy, iz, bx != 0ull, by != 0ull, bz != 0ull, pl, st.lds - __lane_id(), c);
+    else traverse_packet_pairs<PROGRAM>(sc, ray, ix, iy, iz, bx != 0ull, by != 0ull, bz != 0ull, pl, st.lds - __lane_id());
   } else {
     traverse<PROGRAM, DEEP, STATS, false>(sc, ray, false, 0, pl, st, c);
   }
