@@ -455,7 +455,7 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
   const int lane = (int)__lane_id();
   const u64 all = __builtin_amdgcn_ballot_w64(true);
   const int leader = __ffsll((long long)all) - 1;
-  const uint32_t negBitsU = (nxU ? 1u : 0u) | (nyU ? 2u : 0u) | (nzU ? 4u : 0u);
+  const uint32_t negBitsU = (uint32_t)__builtin_amdgcn_readfirstlane((int)((nxU ? 1u : 0u) | (nyU ? 2u : 0u) | (nzU ? 4u : 0u)));
   auto leaf_test = [&](uint32_t off, u64 m) {
     if ((m >> lane) & 1ull) {
       const ConstF4 t = tris + 3 * (size_t)off;
@@ -483,10 +483,14 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
     const F16v pr = *(ConstF16)(pairs + 4 * (size_t)ci);
     const u64 hmL = __builtin_amdgcn_ballot_w64(box_test_finite(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz)) & mask;
     const u64 hmR = __builtin_amdgcn_ballot_w64(box_test_finite(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz)) & mask;
-    const bool neg = (negBitsU >> axis) & 1u;
+    // everything below is wave-uniform; integer selects on values the compiler can see are scalar (a select between two of
+    // the loaded floats, or on a bool it cannot prove uniform, becomes v_cndmask + readfirstlane)
+    const bool neg = ((negBitsU >> axis) & 1u) != 0u;
     const u64 hmN = neg ? hmR : hmL, hmF = neg ? hmL : hmR;
-    const uint32_t refN = __float_as_uint(neg ? pr.se : pr.s6), refF = __float_as_uint(neg ? pr.s6 : pr.se);
-    const uint32_t metaN = __float_as_uint(neg ? pr.sf : pr.s7), metaF = __float_as_uint(neg ? pr.s7 : pr.sf);
+    const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
+    const uint32_t metaL = __float_as_uint(pr.s7), metaR = __float_as_uint(pr.sf);
+    const uint32_t refN = neg ? refR : refL, refF = neg ? refL : refR;
+    const uint32_t metaN = neg ? metaR : metaL, metaF = neg ? metaL : metaR;
     const bool leafN = (metaN & 0xffffu) != 0u, leafF = (metaF & 0xffffu) != 0u;
     const uint32_t entF = leafF ? (kLeafTag | refF) : (refF | (((metaF >> 16) & 3u) << 29));
     bool haveNext = false;
