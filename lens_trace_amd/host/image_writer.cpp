@@ -26,7 +26,7 @@ const uint8_t kChromaQ[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99
                               99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
 
 struct Huffman {
-  uint32_t freq[257] = {0};
+  uint64_t freq[257] = {0};
   uint8_t bits[17] = {0};      // bits[l] = number of codes of length l
   std::vector<uint8_t> vals;   // symbols in code order
   uint16_t code[256] = {0};
@@ -34,16 +34,16 @@ struct Huffman {
 
   // T.81 Annex K.2: code sizes from frequencies (with the reserved all-ones code point), limited to 16 bits
   void build() {
-    uint32_t f[257];
+    uint64_t f[257];
     int codesize[257] = {0}, others[257];
     memcpy(f, freq, sizeof f);
     for (int i = 0; i < 257; i++) others[i] = -1;
     f[256] = 1;   // guarantees that no real symbol gets the all-ones code
     for (;;) {
       int c1 = -1, c2 = -1;
-      uint32_t v = 0xffffffffu;
+      uint64_t v = ~0ull;
       for (int i = 0; i <= 256; i++) if (f[i] && f[i] <= v) { v = f[i]; c1 = i; }
-      v = 0xffffffffu;
+      v = ~0ull;
       for (int i = 0; i <= 256; i++) if (f[i] && f[i] <= v && i != c1) { v = f[i]; c2 = i; }
       if (c2 < 0) break;
       f[c1] += f[c2];
@@ -54,9 +54,9 @@ struct Huffman {
       codesize[c2]++;
       while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
     }
-    int count[64] = {0};
+    int count[258] = {0};   // (a code can be no longer than the number of symbols)
     for (int i = 0; i <= 256; i++) if (codesize[i]) count[codesize[i]]++;
-    for (int i = 63; i > 16; i--) {
+    for (int i = 257; i > 16; i--) {
       while (count[i] > 0) {
         int j = i - 2;
         while (count[j] == 0) j--;
@@ -71,7 +71,7 @@ struct Huffman {
     count[l]--;   // drop the reserved code point
     for (int i = 1; i <= 16; i++) bits[i] = (uint8_t)count[i];
     vals.clear();
-    for (int len = 1; len <= 63; len++)
+    for (int len = 1; len <= 257; len++)
       for (int i = 0; i < 256; i++) if (codesize[i] == len) vals.push_back((uint8_t)i);
     uint16_t c = 0;
     size_t k = 0;
