@@ -1,6 +1,8 @@
 """GPU edge cases (-m gpu): the situations the reference's quirks and this backend's own
 special paths (DEEP stack spill, non-finite rays, host-side validation) create, each against the CPU oracle bit for bit,
 plus a seeded fuzz over random small scenes, cameras and programs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -163,7 +165,7 @@ def test_axis_parallel_and_degenerate_rays(renderer):
             both(renderer, s, prog, 32, 32, cam)                       # even size: x = 16 -> film.x = 0 exactly
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LT_FUZZ_SEEDS", "12"))))   # LT_FUZZ_SEEDS=300 for a long soak
 def test_fuzz_random_scenes(renderer, monkeypatch, seed):
     monkeypatch.setenv("LT_GI_MEGAKERNEL", str(seed % 2))       # alternate the two GI execution paths
     rng = np.random.default_rng(1000 + seed)
