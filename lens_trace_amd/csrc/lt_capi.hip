@@ -584,6 +584,134 @@ static int ensure_square_order(lt_hip_context* ctx, const lt_hip_render_desc* d,
   return LT_OK;
 }
 
+// The wavefront GI pipeline for one iteration of render_on_stream's frame loop: one set of stage launches for the
+// fp.fusedFrames frames of the single-sample program (samplesPerSet == 0; colours go to stageOut), or ceil(25 / samplesPerSet)
+// sets for the 25 samples of the one frame of the 25-sample variant (raw colours to ctx->d_samples, blended into `image`).
+static int launch_gi_sets(lt_hip_context* ctx, hipStream_t s, const SceneDev& sc, const FrameParams& fp, const LaunchConfig& lc, uint32_t lds,
+                          uint64_t giPixels, uint32_t samplesPerSet, uint64_t floats, float* stageOut, float* image, uint32_t& launches) {
+  const bool gi25 = samplesPerSet != 0u;
+  const uint32_t sets = gi25 ? (25u + samplesPerSet - 1u) / samplesPerSet : 1u;
+  for (uint32_t set = 0; set < sets; set++) {
+    const uint32_t k0 = set * samplesPerSet;
+    FrameParams fs = fp;
+    float* blendOut = nullptr;
+    float* out = stageOut;
+    uint32_t sample = fp.frameCount;
+    if (gi25) {
+      fs.fusedFrames = std::min(samplesPerSet, 25u - k0);
+      fs.frameStride = floats;
+      fs.accumulateN = -1;
+      blendOut = image;
+      out = ctx->d_samples;
+      sample = fp.frameCount * 32u + k0;
+    }
+    int rc;
+    if (lc.deep) rc = lc.devlibm ? launch_gi_sample<Config<true, false, true>>(ctx, s, sc, fs, out, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches)
+                                 : launch_gi_sample<Config<true, false, false>>(ctx, s, sc, fs, out, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches);
+    else rc = lc.devlibm ? launch_gi_sample<Config<false, false, true>>(ctx, s, sc, fs, out, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches)
+                         : launch_gi_sample<Config<false, false, false>>(ctx, s, sc, fs, out, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches);
+    if (rc) return rc;
+  }
+  return LT_OK;
+}
+
+// Folds the nf sample images a fused launch left in ctx->d_samples into `out` (timed by its own event pair, so that
+// lt_hip_stats::render_ms can leave it out).
+static int launch_running_mean(lt_hip_context* ctx, hipStream_t s, const FrameParams& fp, uint64_t floats, uint32_t nf, int32_t base,
+                               bool paddedTiles, float* out) {
+  const uint32_t threads = 256;
+  while (ctx->mean_events.size() < 2 * (size_t)(ctx->mean_pairs + 1)) {
+    hipEvent_t e;
+    LT_HIP_CHECK(ctx, hipEventCreate(&e));
+    ctx->mean_events.push_back(e);
+  }
+  LT_HIP_CHECK(ctx, hipEventRecord(ctx->mean_events[2 * ctx->mean_pairs], s));
+  lt_running_mean_kernel<<<dim3((uint32_t)((floats + threads - 1) / threads)), dim3(threads), 0, s>>>(ctx->d_samples, nf, floats, out, floats,
+                                                                                                  base, fp, paddedTiles ? 1 : 0);
+  LT_HIP_CHECK(ctx, hipGetLastError());
+  LT_HIP_CHECK(ctx, hipEventRecord(ctx->mean_events[2 * ctx->mean_pairs + 1], s));
+  ctx->mean_pairs++;
+  return LT_OK;
+}
+
+// How a call is cut into launches (render_on_stream): which execution path the global-illumination programs take, how many
+// frames (or, for the 25-sample variant, samples of one frame) travel through one launch, and the scratch memory for them.
+struct FusionPlan {
+  bool giWavefront = false;     // wavefront pipeline instead of the one-lane-per-pixel kernel
+  bool gi25Sets = false;        // 25-sample variant through the pipeline: samplesPerSet samples per set of stage launches
+  uint32_t chunk = 1;           // frames per launch (> 1: fused; lt_running_mean_kernel folds them)
+  uint32_t samplesPerSet = 0;
+  uint64_t giPixels = 0;        // compact output pixels of one frame
+};
+
+static int plan_fusion(lt_hip_context* ctx, const lt_hip_render_desc* d, const TilePlan& p, uint32_t frames, uint64_t nblocks, bool stats,
+                       bool persistent, int giMaxDepth, FusionPlan& out) {
+  // The global-illumination programs run as a wavefront pipeline with path compaction when the scene is big enough for the
+  // traversal to dominate the ~18 launches and the queue traffic per sample (1 M-triangle wall at 4K, 16 bounces: 31 ms
+  // against 52 ms for the one-lane-per-pixel kernel; 42-triangle Cornell box at 1080p: 3.5 ms against 2.7 ms), or when the
+  // launches serve many frames at once and paths are long (Cornell 1080p, 16 frames per call: 1.55 ms against 1.89 ms per
+  // sample at 16 bounces, but 1.12 against 0.78 ms at 4; the 25 samples of one frame of the 25-sample variant count as many:
+  // 37 against 55 ms at 16 bounces, 27.5 against 21 ms at 4), and never when work is being counted (the counting kernels
+  // re-trace like the reference does).  LT_GI_MEGAKERNEL=1 / =0 force one or the other (A/B measurements, tests of both
+  // paths on small scenes).
+  const char* ge = getenv("LT_GI_MEGAKERNEL");
+  const bool giProgram = d->program == LT_PROGRAM_GLOBAL_ILLUMINATION || d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25;
+  const bool giManyLongPaths = giMaxDepth > 8 && (d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25 ||
+                                                    (d->program == LT_PROGRAM_GLOBAL_ILLUMINATION && frames > 1 && d->accumulate));
+  const bool giWavefront = giProgram && !stats && nblocks > 0 && (ge ? atoi(ge) == 0 : (ctx->n_prims >= 1024u || giManyLongPaths));
+  const uint64_t giPixels = (uint64_t)p.tilesInCall * p.tileW * p.tileH;
+  if (giWavefront && giPixels > 0xffffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many pixels for the GI path queues");
+  // Several samples of a running mean in ONE launch.  A launch cannot end before its slowest wavefront does -- one 8x8 square
+  // is a dependent chain of several hundred node fetches, ~0.3-0.6 ms on the 1 M-triangle scene, 1.9 ms for the squares on
+  // the image's centre column -- so a launch per sample pays that drain once per sample: 0.65 ms of a 4.5 ms launch for the
+  // whole 4K frame, and of a 1.2 ms launch for one GPU's eighth of it.  Fused, the work items are (frame, square) pairs, all
+  // independent: each stores its un-accumulated colour in its frame's slice of a scratch buffer and lt_running_mean_kernel
+  // folds the slices in frame order afterwards (same arithmetic, same order: bit-identical).  LT_FUSED_FRAMES=0 turns it
+  // off (A/B measurements), LT_FUSED_BYTES caps the scratch memory (default 16 GiB of the 288; tests use it to force chunks).
+  // The wavefront GI pipeline fuses the same way (single-sample program only: the 25-sample blend is sequential per pixel):
+  // its ~18 stage launches then serve all frames of a chunk, each path carrying its frame; its per-frame scratch is the path
+  // queues and the direct / indirect images (11 arrays of 16 bytes per pixel) besides the sample image.
+  // The 25-sample variant fuses the samples of ONE frame instead (its frames stay sequential): `chunk` is then the number of
+  // samples k per set of launches, and lt_gi_blend25_kernel replaces the running mean.
+  uint32_t chunk = 1;
+  const bool giFusable = giWavefront && d->program == LT_PROGRAM_GLOBAL_ILLUMINATION;
+  const bool gi25Sets = giWavefront && d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25;
+  if (gi25Sets || ((giFusable || (persistent && !giWavefront)) && !stats && frames > 1 && d->accumulate && nblocks > 0)) {
+    const char* fe = getenv("LT_FUSED_FRAMES");
+    const char* fb = getenv("LT_FUSED_BYTES");
+    const uint64_t cap = fb ? strtoull(fb, nullptr, 10) : (16ull << 30);
+    const uint64_t frameBytes = p.floats * sizeof(float);
+    const uint64_t scratchPerFrame = frameBytes + (giWavefront ? giPixels * 16 * 11 : 0);
+    if (!(fe && atoi(fe) == 0) && frameBytes > 0)
+      chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(gi25Sets ? 25u : frames), cap / scratchPerFrame, 0xffffffffull / nblocks,
+                                                                  giWavefront ? 0xffffffffull / std::max<uint64_t>(giPixels, 1) : ~0ull}));
+    if ((chunk > 1 || gi25Sets) && ctx->d_samples_bytes < chunk * frameBytes) {
+      if (ctx->d_samples) LT_HIP_CHECK(ctx, hipFree(ctx->d_samples));
+      ctx->d_samples = nullptr;
+      ctx->d_samples_bytes = 0;
+      // a device that cannot spare the scratch memory gets shorter launches, down to one sample per launch
+      while ((chunk > 1 || gi25Sets) && hipMalloc((void**)&ctx->d_samples, chunk * frameBytes) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->d_samples = nullptr;
+        if (chunk == 1) return fail(ctx, LT_ERR_HIP, "out of device memory for one sample image");
+        chunk /= 2;
+      }
+      ctx->d_samples_bytes = ctx->d_samples ? chunk * frameBytes : 0;
+    }
+  }
+  if (giWavefront) {
+    int erc;
+    while ((erc = ensure_gi_buffers(ctx, giPixels * chunk)) != LT_OK && chunk > 1) chunk /= 2;   // (frees what it got, retries smaller)
+    if (erc) return erc;
+  }
+  out.giWavefront = giWavefront;
+  out.gi25Sets = gi25Sets;
+  out.giPixels = giPixels;
+  out.samplesPerSet = gi25Sets ? chunk : 0u;   // 25-sample variant: samples k per set of stage launches
+  out.chunk = gi25Sets ? 1u : chunk;           // ... and its frames stay one per iteration of the caller's loop
+  return LT_OK;
+}
+
 static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, float* out_device, uint64_t out_bytes, hipStream_t s) {
   if (!ctx) return LT_ERR_INVALID_ARGUMENT;
   if (!ctx->has_scene) return fail(ctx, LT_ERR_NO_SCENE, "lt_hip_render before lt_hip_set_scene");
@@ -663,67 +791,14 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
     const int orc = ensure_square_order(ctx, d, p, fp.sinYaw == 0.0f, s, &fp.order, fp.orderHead);
     if (orc) return orc;
   }
-  // The global-illumination programs run as a wavefront pipeline with path compaction when the scene is big enough for the
-  // traversal to dominate the ~18 launches and the queue traffic per sample (1 M-triangle wall at 4K, 16 bounces: 31 ms
-  // against 52 ms for the one-lane-per-pixel kernel; 42-triangle Cornell box at 1080p: 3.5 ms against 2.7 ms), or when the
-  // launches serve many frames at once and paths are long (Cornell 1080p, 16 frames per call: 1.55 ms against 1.89 ms per
-  // sample at 16 bounces, but 1.12 against 0.78 ms at 4; the 25 samples of one frame of the 25-sample variant count as many:
-  // 37 against 55 ms at 16 bounces, 27.5 against 21 ms at 4), and never when work is being counted (the counting kernels
-  // re-trace like the reference does).  LT_GI_MEGAKERNEL=1 / =0 force one or the other (A/B measurements, tests of both
-  // paths on small scenes).
-  const char* ge = getenv("LT_GI_MEGAKERNEL");
-  const bool giProgram = d->program == LT_PROGRAM_GLOBAL_ILLUMINATION || d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25;
-  const bool giManyLongPaths = fp.giMaxDepth > 8 && (d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25 ||
-                                                    (d->program == LT_PROGRAM_GLOBAL_ILLUMINATION && frames > 1 && d->accumulate));
-  const bool giWavefront = giProgram && !stats && nblocks > 0 && (ge ? atoi(ge) == 0 : (ctx->n_prims >= 1024u || giManyLongPaths));
-  const uint64_t giPixels = (uint64_t)p.tilesInCall * p.tileW * p.tileH;
-  if (giWavefront && giPixels > 0xffffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many pixels for the GI path queues");
-  // Several samples of a running mean in ONE launch.  A launch cannot end before its slowest wavefront does -- one 8x8 square
-  // is a dependent chain of several hundred node fetches, ~0.3-0.6 ms on the 1 M-triangle scene, 1.9 ms for the squares on
-  // the image's centre column -- so a launch per sample pays that drain once per sample: 0.65 ms of a 4.5 ms launch for the
-  // whole 4K frame, and of a 1.2 ms launch for one GPU's eighth of it.  Fused, the work items are (frame, square) pairs, all
-  // independent: each stores its un-accumulated colour in its frame's slice of a scratch buffer and lt_running_mean_kernel
-  // folds the slices in frame order afterwards (same arithmetic, same order: bit-identical).  LT_FUSED_FRAMES=0 turns it
-  // off (A/B measurements), LT_FUSED_BYTES caps the scratch memory (default 16 GiB of the 288; tests use it to force chunks).
-  // The wavefront GI pipeline fuses the same way (single-sample program only: the 25-sample blend is sequential per pixel):
-  // its ~18 stage launches then serve all frames of a chunk, each path carrying its frame; its per-frame scratch is the path
-  // queues and the direct / indirect images (11 arrays of 16 bytes per pixel) besides the sample image.
-  // The 25-sample variant fuses the samples of ONE frame instead (its frames stay sequential): `chunk` is then the number of
-  // samples k per set of launches, and lt_gi_blend25_kernel replaces the running mean.
-  uint32_t chunk = 1;
-  const bool giFusable = giWavefront && d->program == LT_PROGRAM_GLOBAL_ILLUMINATION;
-  const bool gi25Sets = giWavefront && d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25;
-  if (gi25Sets || ((giFusable || (persistent && !giWavefront)) && !stats && frames > 1 && d->accumulate && nblocks > 0)) {
-    const char* fe = getenv("LT_FUSED_FRAMES");
-    const char* fb = getenv("LT_FUSED_BYTES");
-    const uint64_t cap = fb ? strtoull(fb, nullptr, 10) : (16ull << 30);
-    const uint64_t frameBytes = p.floats * sizeof(float);
-    const uint64_t scratchPerFrame = frameBytes + (giWavefront ? giPixels * 16 * 11 : 0);
-    if (!(fe && atoi(fe) == 0) && frameBytes > 0)
-      chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(gi25Sets ? 25u : frames), cap / scratchPerFrame, 0xffffffffull / nblocks,
-                                                                  giWavefront ? 0xffffffffull / std::max<uint64_t>(giPixels, 1) : ~0ull}));
-    if ((chunk > 1 || gi25Sets) && ctx->d_samples_bytes < chunk * frameBytes) {
-      if (ctx->d_samples) LT_HIP_CHECK(ctx, hipFree(ctx->d_samples));
-      ctx->d_samples = nullptr;
-      ctx->d_samples_bytes = 0;
-      // a device that cannot spare the scratch memory gets shorter launches, down to one sample per launch
-      while ((chunk > 1 || gi25Sets) && hipMalloc((void**)&ctx->d_samples, chunk * frameBytes) != hipSuccess) {
-        (void)hipGetLastError();
-        ctx->d_samples = nullptr;
-        if (chunk == 1) return fail(ctx, LT_ERR_HIP, "out of device memory for one sample image");
-        chunk /= 2;
-      }
-      ctx->d_samples_bytes = ctx->d_samples ? chunk * frameBytes : 0;
-    }
+  FusionPlan fu;
+  {
+    const int frc = plan_fusion(ctx, d, p, frames, nblocks, stats, persistent, fp.giMaxDepth, fu);
+    if (frc) return frc;
   }
-  if (giWavefront) {
-    int erc;
-    while ((erc = ensure_gi_buffers(ctx, giPixels * chunk)) != LT_OK && chunk > 1) chunk /= 2;   // (frees what it got, retries smaller)
-    if (erc) return erc;
-  }
-  const uint32_t samplesPerSet = gi25Sets ? chunk : 0u;   // 25-sample variant: samples k per set of stage launches
-  if (gi25Sets) chunk = 1;                                // ... and its frames stay one per iteration of the loop below
-  const bool fused = chunk > 1;
+  const bool giWavefront = fu.giWavefront, gi25Sets = fu.gi25Sets, fused = fu.chunk > 1;
+  const uint32_t chunk = fu.chunk, samplesPerSet = fu.samplesPerSet;
+  const uint64_t giPixels = fu.giPixels;
   const bool paddedTiles = d->width % p.tileW != 0 || d->height % p.tileH != 0;
   ctx->mean_pairs = 0;
   LT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, s));
@@ -746,30 +821,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       uint32_t lds = (uint32_t)std::max(1, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
       if (giWavefront) {
-        // one set of stage launches for the nf frames of this iteration, or ceil(25 / samplesPerSet) sets for the 25 samples
-        // of its single frame
-        const uint32_t sets = gi25Sets ? (25u + samplesPerSet - 1u) / samplesPerSet : 1u;
-        for (uint32_t set = 0; set < sets; set++) {
-          const uint32_t k0 = set * samplesPerSet;
-          FrameParams fs = fp;
-          float* blendOut = nullptr;
-          float* stageOut = out_launch;
-          uint32_t sample = fp.frameCount;
-          if (gi25Sets) {
-            fs.fusedFrames = std::min(samplesPerSet, 25u - k0);
-            fs.frameStride = p.floats;
-            fs.accumulateN = -1;
-            blendOut = out_device;
-            stageOut = ctx->d_samples;
-            sample = fp.frameCount * 32u + k0;
-          }
-          int grc;
-          if (deep) grc = devlibm ? launch_gi_sample<Config<true, false, true>>(ctx, s, sc, fs, stageOut, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches)
-                                  : launch_gi_sample<Config<true, false, false>>(ctx, s, sc, fs, stageOut, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches);
-          else grc = devlibm ? launch_gi_sample<Config<false, false, true>>(ctx, s, sc, fs, stageOut, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches)
-                             : launch_gi_sample<Config<false, false, false>>(ctx, s, sc, fs, stageOut, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches);
-          if (grc) return grc;
-        }
+        const int grc = launch_gi_sets(ctx, s, sc, fp, lc, lds, giPixels, gi25Sets ? samplesPerSet : 0u, p.floats, out_launch, out_device, launches);
+        if (grc) return grc;
         launches--;   // (counted again below)
       } else if (userProgram) {
         const lt_hip_context::UserProgram& up = ctx->user_programs[d->program - LT_PROGRAM_USER_BASE];
@@ -788,18 +841,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       LT_HIP_CHECK(ctx, hipGetLastError());
       launches++;
       if (fused) {
-        const uint32_t threads = 256;
-        while (ctx->mean_events.size() < 2 * (size_t)(ctx->mean_pairs + 1)) {
-          hipEvent_t e;
-          LT_HIP_CHECK(ctx, hipEventCreate(&e));
-          ctx->mean_events.push_back(e);
-        }
-        LT_HIP_CHECK(ctx, hipEventRecord(ctx->mean_events[2 * ctx->mean_pairs], s));
-        lt_running_mean_kernel<<<dim3((uint32_t)((p.floats + threads - 1) / threads)), dim3(threads), 0, s>>>(
-            ctx->d_samples, nf, p.floats, out_device, p.floats, (int32_t)(d->accumulate_base + firstFrame), fp, paddedTiles ? 1 : 0);
-        LT_HIP_CHECK(ctx, hipGetLastError());
-        LT_HIP_CHECK(ctx, hipEventRecord(ctx->mean_events[2 * ctx->mean_pairs + 1], s));
-        ctx->mean_pairs++;
+        const int mrc = launch_running_mean(ctx, s, fp, p.floats, nf, (int32_t)(d->accumulate_base + firstFrame), paddedTiles, out_device);
+        if (mrc) return mrc;
       }
     }
   }
