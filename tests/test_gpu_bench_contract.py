@@ -1,0 +1,54 @@
+"""GPU test (-m gpu) of bench.py's output contract on a reduced workload: one JSON line with the driver's keys, the roofline
+and cpu_baseline objects, and the two-rank path (two processes sharing this GPU through gloo: LT_BENCH_BACKEND=gloo,
+LT_BENCH_SINGLE_DEVICE=1) producing the same ray count as one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--cells", "64", "--width", "640", "--height", "360", "--spp", "4", "--steps", "2", "--warmup", "1"]
+
+
+def run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, cwd=ROOT, env=e, check=True, capture_output=True, text=True, timeout=600).stdout
+    lines = [line for line in out.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_keys():
+    d = run([sys.executable, "bench.py", "--gpus", "1"] + SMALL)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "Mrays/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and d["config"]["spp"] == 4
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches_per_step"] == 1.0 and r["samples_per_launch"] == 4.0      # all samples of a step in one launch
+    assert r["traffic"] is None                                                   # no PMC measurement for this reduced workload
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "frames" in c["sample"]
+    assert d["value"] > c["value"]
+    # rays = one camera ray per pixel + one shadow ray per hit that is not a light, per sample
+    px = 640 * 360 * 4
+    assert px <= d["config"]["rays_per_frame"] <= 2 * px
+
+
+def test_two_ranks_on_one_gpu_through_gloo_count_the_same_rays():
+    one = run([sys.executable, "bench.py", "--gpus", "1", "--no-cpu-baseline"] + SMALL)
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29541", "bench.py", "--gpus", "2", "--no-cpu-baseline"] + SMALL,
+              env={"LT_BENCH_BACKEND": "gloo", "LT_BENCH_SINGLE_DEVICE": "1"})
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+    assert "tiles interleaved over 2 GPUs" in two["config"]["workload"]
+    assert "cpu_baseline" not in two
