@@ -203,3 +203,55 @@ def test_wavefront_gi25_sample_sets(renderer, cornell, monkeypatch):
     monkeypatch.setenv("LT_GI_MEGAKERNEL", "1")
     got, launches = once()
     assert launches == 1 and np.array_equal(got, want)
+
+
+# ---- randomised scheduling configurations: whatever the launch plan, the pixels are those of one launch per sample ----
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LT_FUZZ_SEEDS", "16"))))
+def test_random_scheduling_configurations(renderer, cornell, monkeypatch, seed):
+    import torch
+    rng = np.random.default_rng(7000 + seed)
+    prog_name, prog_id, path = [("accumulator", C.PROGRAM_ACCUMULATOR, ACC), ("global_illumination", C.PROGRAM_GLOBAL_ILLUMINATION, GI),
+                                ("basic_lighting", C.PROGRAM_BASIC_LIGHTING, "resources/kernels/opencl/basic_lighting.cl"),
+                                ("global_illumination25", C.PROGRAM_GLOBAL_ILLUMINATION_25, "resources/kernels/opencl/global_illumination.cl")][seed % 4]
+    heavy = prog_id in (C.PROGRAM_BASIC_LIGHTING, C.PROGRAM_GLOBAL_ILLUMINATION_25)
+    W, H = int(rng.integers(1, 40 if heavy else 150)), int(rng.integers(1, 30 if heavy else 100))
+    count = int(rng.integers(2, 5 if heavy else 9))
+    first = int(rng.integers(0, 20))
+    base = int(rng.integers(0, 3))
+    depth = int(rng.integers(1, 17))
+    yaw = float(rng.choice([0.0, 0.0, 0.02]))
+    cam = sc.camera_bytes(float(rng.uniform(-1, 1)) if seed % 3 else 0.0, 2.5, -50.0, yaw, 0.0, 0.0, 1)
+    tile = (int(rng.integers(1, 9)) * 8, int(rng.integers(1, 9)) * 8, int(rng.integers(1, 4)))     # tile_w, tile_h, ranks
+    start = rng.random((H, W, 3), dtype=np.float32)                                                # the accumulator so far (base > 0)
+    renderer.set_scene(cornell)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def render_all(env):
+        for k in ("LT_FUSED_FRAMES", "LT_FUSED_BYTES", "LT_NATURAL_ORDER", "LT_GI_MEGAKERNEL", "LT_PERSISTENT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        whole = start.copy()
+        renderer.render(RenderPropertiesHIP(path, (W, H, 3), whole, cornell, pCamera=cam, frameFirst=first, frameCount=count, accumulate=True,
+                                            accumulateBase=base, giMaxDepth=depth))
+        plan = TilePlan(W, H, 3, tile[0], tile[1], tile[2])
+        stacks = []
+        for r in range(plan.world):
+            d = make_desc(prog_id, W, H, 3, cam, frame_first=first, frame_count=count, accumulate=True, accumulate_base=base,
+                          tile=plan.desc_tile(r), gi_max_depth=depth)
+            buf = torch.from_numpy(tile_stack(plan, r, start)).to("cuda:0")
+            renderer.render_device(d, buf.data_ptr(), plan.floats_per_rank * 4, stream)
+            torch.cuda.synchronize()
+            stacks.append(buf.cpu().numpy())
+        return whole, untile_numpy(plan, stacks)
+
+    from lens_trace_amd.dist import tile_stack_numpy as tile_stack
+    want, want_tiled = render_all({"LT_FUSED_FRAMES": "0", "LT_NATURAL_ORDER": "1", "LT_GI_MEGAKERNEL": "1"})
+    assert np.array_equal(want, want_tiled), (prog_name, W, H, tile)
+    variants = [{}, {"LT_GI_MEGAKERNEL": "0"}, {"LT_GI_MEGAKERNEL": "1"},
+                {"LT_FUSED_BYTES": str(int(rng.integers(1, 6)) * (W * H * 3 * 4 + W * H * 176) + 7), "LT_GI_MEGAKERNEL": str(seed % 2)},
+                {"LT_PERSISTENT": "0"}]
+    for env in variants:
+        got, got_tiled = render_all(env)
+        assert np.array_equal(got, want), (prog_name, W, H, count, first, base, depth, env)
+        assert np.array_equal(got_tiled, want), (prog_name, W, H, count, first, base, depth, tile, env)
