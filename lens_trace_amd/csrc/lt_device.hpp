@@ -263,6 +263,21 @@ __device__ __forceinline__ bool box_test_finite(float lox, float loy, float loz,
   return tEnter <= tExit && tExit > 0.0f;
 }
 
+// box_test_finite for a ray whose direction signs are known at compile time (NEG bit a = direction component a is negative):
+// the entry plane of an axis is then the box's max (negative direction) or min, no v_min / v_max needed.  Same predicate:
+// (bound - o) * inv is monotonic in bound, so the selected product IS the min (or max) of the two, up to the sign of a zero,
+// which neither max3 / min3 nor the two compares can tell apart.
+template <int NEG>
+__device__ __forceinline__ bool box_test_signed(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray& ray,
+                                                float ix, float iy, float iz) {
+  const float nearX = (NEG & 1) ? hix : lox, farX = (NEG & 1) ? lox : hix;
+  const float nearY = (NEG & 2) ? hiy : loy, farY = (NEG & 2) ? loy : hiy;
+  const float nearZ = (NEG & 4) ? hiz : loz, farZ = (NEG & 4) ? loz : hiz;
+  const float tEnter = __builtin_fmaxf(__builtin_fmaxf((nearX - ray.o.x) * ix, (nearY - ray.o.y) * iy), (nearZ - ray.o.z) * iz);
+  const float tExit = __builtin_fminf(__builtin_fminf((farX - ray.o.x) * ix, (farY - ray.o.y) * iy), (farZ - ray.o.z) * iz);
+  return tEnter <= tExit && tExit > 0.0f;
+}
+
 template <bool FINITE>
 __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray& ray, float ix,
                                          float iy, float iz, bool nx, bool ny, bool nz) {
@@ -444,9 +459,8 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
 // 64-byte scalar load serves two slab tests and the walk makes half the dependent fetches.  Order per lane is the
 // reference's: the near child's subtree (or leaf) completely before the far child's; a far child that must wait goes on
 // the wave-uniform stack with the mask of the lanes that hit it (a leaf as 0x80000000 | primitive offset).
-template <int PROGRAM>
-__device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool nxU, bool nyU,
-                                             bool nzU, Hit& pl, int* ldsWave) {
+template <int PROGRAM, int NEG>
+__device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, Hit& pl, int* ldsWave) {
   using u64 = unsigned long long;
   constexpr uint32_t kLeafTag = 0x80000000u;
   const ConstF4 nodes = (ConstF4)(unsigned long long)sc.nodes;
@@ -455,7 +469,7 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
   const int lane = (int)__lane_id();
   const u64 all = __builtin_amdgcn_ballot_w64(true);
   const int leader = __ffsll((long long)all) - 1;
-  const uint32_t negBitsU = (uint32_t)__builtin_amdgcn_readfirstlane((int)((nxU ? 1u : 0u) | (nyU ? 2u : 0u) | (nzU ? 4u : 0u)));
+  constexpr uint32_t negBitsU = (uint32_t)NEG;   // the direction signs the whole wave shares, a compile-time constant here
   auto leaf_test = [&](uint32_t off, u64 m) {
     if ((m >> lane) & 1ull) {
       const ConstF4 t = tris + 3 * (size_t)off;
@@ -470,7 +484,7 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
   uint32_t cur;   // interior node: index | axis << 29
   {
     const F8v nd = *(ConstF8)(nodes);
-    mask = __builtin_amdgcn_ballot_w64(box_test_finite(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz));
+    mask = __builtin_amdgcn_ballot_w64(box_test_signed<NEG>(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz));
     if (mask == 0ull) return;
     const uint32_t meta = __float_as_uint(nd.s7);
     if ((meta & 0xffffu) != 0u) { leaf_test(__float_as_uint(nd.s6), mask); return; }
@@ -481,8 +495,8 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
     const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));
     const uint32_t axis = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur >> 29));
     const F16v pr = *(ConstF16)(pairs + 4 * (size_t)ci);
-    const u64 hmL = __builtin_amdgcn_ballot_w64(box_test_finite(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz)) & mask;
-    const u64 hmR = __builtin_amdgcn_ballot_w64(box_test_finite(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz)) & mask;
+    const u64 hmL = __builtin_amdgcn_ballot_w64(box_test_signed<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz)) & mask;
+    const u64 hmR = __builtin_amdgcn_ballot_w64(box_test_signed<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz)) & mask;
     // everything below is wave-uniform; integer selects on values the compiler can see are scalar (a select between two of
     // the loaded floats, or on a bool it cannot prove uniform, becomes v_cndmask + readfirstlane)
     const bool neg = ((negBitsU >> axis) & 1u) != 0u;
@@ -558,7 +572,19 @@ __device__ inline void traverse_camera(const SceneDev& sc, const Ray& ray, Hit& 
     // two nodes per iteration from the child-pair records; the counting kernels keep the one-node walk, whose stack entries
     // need no leaf counts
     if (STATS) traverse_packet<PROGRAM, STATS>(sc, ray, ix, iy, iz, bx != 0ull, by != 0ull, bz != 0ull, pl, st.lds - __lane_id(), c);
-    else traverse_packet_pairs<PROGRAM>(sc, ray, ix, iy, iz, bx != 0ull, by != 0ull, bz != 0ull, pl, st.lds - __lane_id());
+    else {
+      int* const row = st.lds - __lane_id();
+      switch ((bx != 0ull ? 1 : 0) | (by != 0ull ? 2 : 0) | (bz != 0ull ? 4 : 0)) {   // one specialisation per sign octant
+        case 0: traverse_packet_pairs<PROGRAM, 0>(sc, ray, ix, iy, iz, pl, row); break;
+        case 1: traverse_packet_pairs<PROGRAM, 1>(sc, ray, ix, iy, iz, pl, row); break;
+        case 2: traverse_packet_pairs<PROGRAM, 2>(sc, ray, ix, iy, iz, pl, row); break;
+        case 3: traverse_packet_pairs<PROGRAM, 3>(sc, ray, ix, iy, iz, pl, row); break;
+        case 4: traverse_packet_pairs<PROGRAM, 4>(sc, ray, ix, iy, iz, pl, row); break;
+        case 5: traverse_packet_pairs<PROGRAM, 5>(sc, ray, ix, iy, iz, pl, row); break;
+        case 6: traverse_packet_pairs<PROGRAM, 6>(sc, ray, ix, iy, iz, pl, row); break;
+        default: traverse_packet_pairs<PROGRAM, 7>(sc, ray, ix, iy, iz, pl, row); break;
+      }
+    }
   } else {
     traverse<PROGRAM, DEEP, STATS, false>(sc, ray, false, 0, pl, st, c);
   }
