@@ -188,7 +188,9 @@ def main():
         my_alg_bytes_per_launch = my_alg_bytes_per_step / launches_per_step
         achieved = my_alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
         out = {
-            "metric": "Mrays/s (primary+secondary+shadow), 1M-tri @4K",
+            # BASELINE.json's metric on its configuration; other --scene / --width / --height runs say what they ran
+            "metric": "Mrays/s (primary+secondary+shadow), %s @%s" % (
+                "1M-tri" if 990000 <= scene.n_prims <= 1010000 else "%d-tri" % scene.n_prims, "4K" if (W, H) == (3840, 2160) else "%dx%d" % (W, H)),
             "value": round(mrays, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -212,7 +214,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic("%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program)) if world == 1 else None,
-                         "kernel": "lt_render_kernel<accumulator>", "launch_ms": round(launch_ms, 4),
+                         "kernel": "lt_render_kernel<%s>" % args.program if launches_per_step <= args.spp else "wavefront GI pipeline (all its stage kernels)",
+                         "launch_ms": round(launch_ms, 4),
                          "launches_per_step": launches_per_step, "samples_per_launch": args.spp / launches_per_step,
                          "algorithmic_bytes_per_launch": my_alg_bytes_per_launch},
         }
