@@ -459,6 +459,8 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
 // 64-byte scalar load serves two slab tests and the walk makes half the dependent fetches.  Order per lane is the
 // reference's: the near child's subtree (or leaf) completely before the far child's; a far child that must wait goes on
 // the wave-uniform stack with the mask of the lanes that hit it (a leaf as 0x80000000 | primitive offset).
+// NEG is the direction-sign octant the wave's rays share (bit a = component a negative; traverse_camera switches on it): with
+// the signs known at compile time the slab test picks each axis' entry plane directly (box_test_signed).
 template <int PROGRAM, int NEG>
 __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, Hit& pl, int* ldsWave) {
   using u64 = unsigned long long;
