@@ -461,7 +461,8 @@ static void launch_program(const LaunchConfig& k, dim3 grid, uint32_t lds, hipSt
 #undef LT_LAUNCH
 }
 
-constexpr uint32_t kGiCtlWords = 8 + 2 * (kMaxStack + 2);   // 8 per-XCD square queues, queue lengths, bounce work counters
+// 8 per-XCD square queues, queue lengths, bounce work counters: every counter in a cache line of its own
+constexpr uint32_t kGiCtlWords = (8 + 2 * (kMaxStack + 2)) * kQueueStride;
 
 static int ensure_gi_buffers(lt_hip_context* ctx, uint64_t pixels) {
   if (!ctx->d_giCtl) LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_giCtl, kGiCtlWords * sizeof(uint32_t)));
@@ -489,8 +490,8 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   }
   gp.direct = (float4*)ctx->d_gi[8]; gp.indirect = (float4*)ctx->d_gi[9]; gp.blend = (float4*)ctx->d_gi[10];
   uint32_t* queues = ctx->d_giCtl;
-  gp.counts = ctx->d_giCtl + 8;
-  gp.work = ctx->d_giCtl + 8 + (kMaxStack + 2);
+  gp.counts = ctx->d_giCtl + 8 * kQueueStride;
+  gp.work = ctx->d_giCtl + (8 + (kMaxStack + 2)) * kQueueStride;
   gp.sample = sample;
   gp.raw = blend25Out ? 1u : 0u;
   gp.pixels = (uint32_t)pixels;
@@ -790,10 +791,10 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       if (ctx->d_queues) LT_HIP_CHECK(ctx, hipFree(ctx->d_queues));
       ctx->d_queues = nullptr;
       ctx->queue_frames = 0;
-      LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_queues, (size_t)frames * 8 * sizeof(uint32_t)));
+      LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_queues, (size_t)frames * 8 * kQueueStride * sizeof(uint32_t)));
       ctx->queue_frames = frames;
     }
-    LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queues, 0, (size_t)frames * 8 * sizeof(uint32_t), s));
+    LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queues, 0, (size_t)frames * 8 * kQueueStride * sizeof(uint32_t), s));
   }
   fp.totalSquares = (uint32_t)nblocks;
   fp.persistent = persistent;
@@ -827,7 +828,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       f += nf;
       const uint32_t resident = (uint32_t)ctx->cu_count * 32u;   // every wave slot of the chip, once
       const dim3 grid(persistent ? (uint32_t)std::min<uint64_t>(nblocks * nf, resident) : (uint32_t)nblocks);
-      uint32_t* queues = persistent ? ctx->d_queues + (size_t)launchIndex * 8 : nullptr;
+      uint32_t* queues = persistent ? ctx->d_queues + (size_t)launchIndex * 8 * kQueueStride : nullptr;
       // LDS stack rows: a lane never holds more entries than a node has interior ancestors (= bvh_height, validate_scene)
       uint32_t lds = (uint32_t)std::max(1, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments

@@ -28,6 +28,10 @@ namespace lt {
 
 constexpr int kBlock = 64;         // one wavefront per workgroup: a finished wave frees its LDS and wave slot at once
 constexpr int kLdsStack = 32;      // most traversal-stack entries per lane held in LDS (the launch sizes LDS to the scene's BVH height)
+constexpr int kQueueStride = 64;   // dwords between work counters: one 256-byte line each.  (Eight per-XCD counters in one
+                                   // cache line serialise every wave of the chip on one memory channel, 12 ns per work
+                                   // item: 25 ms of a 2-million-item launch, whatever the items cost.  Taking several
+                                   // items per atomic on top of the padding does not pay: -1 % at 4, -2.4 % at 8.)
 constexpr int kMaxStack = 64;      // the reference's nodesToVisit[64] (acc.cl:137)
 constexpr float kFltMax = 3.402823466e+38f;
 

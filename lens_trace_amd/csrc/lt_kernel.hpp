@@ -98,7 +98,7 @@ __device__ __forceinline__ void render_kernel_body(const SceneDev& sc, const Fra
       const uint32_t xcd = (home + sweep) & 7u;
       const uint32_t share = q + (xcd < r ? 1u : 0u), start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
       uint32_t t = 0;
-      if (threadIdx.x == 0) t = atomicAdd(&queues[xcd], 1u);
+      if (threadIdx.x == 0) t = atomicAdd(&queues[xcd * kQueueStride], 1u);
       t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
       if (t >= share * fp.fusedFrames) {   // (share * fusedFrames < 2^32: checked by the host)
         done = ++sweep >= 8u;
@@ -162,8 +162,8 @@ struct GiParams {
   float4* direct;          // per pixel (compact output index): direct colour
   float4* indirect;        // per pixel: indirect sum so far
   float4* blend;           // per pixel: running blend of the 25-sample variant (between chunks of its samples)
-  uint32_t* counts;        // [maxDepth + 1] queue lengths
-  uint32_t* work;          // [maxDepth + 1] chunk counters of the bounce launches
+  uint32_t* counts;        // [maxDepth + 1] queue lengths, kQueueStride dwords apart (one cache line per counter)
+  uint32_t* work;          // [maxDepth + 1] chunk counters of the bounce launches, likewise
   uint32_t sample;         // sampleIndex passed to shade (frameCount, or frameCount*32 + k) of the launch's first frame
   uint32_t raw;            // != 0: the resolve stage stores direct + indirect as is (25-sample variant: lt_gi_blend25_kernel
                            // blends, clamps and accumulates afterwards); 0: it clamps (the frame's own colour is final)
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_primary_kerne
     const uint32_t xcd = (home + sweep) & 7u;
     const uint32_t share = q + (xcd < r ? 1u : 0u), start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
     uint32_t t = 0;
-    if (threadIdx.x == 0) t = atomicAdd(&queues[xcd], 1u);
+    if (threadIdx.x == 0) t = atomicAdd(&queues[xcd * kQueueStride], 1u);
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     if (t >= share * fp.fusedFrames) { sweep++; continue; }
     const uint32_t frame = t / share;   // frame-major inside the XCD's share
@@ -262,11 +262,11 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_bounce_kernel
   st.lds = lds_stack + threadIdx.x;
   Counters c{};
   const GiQueue in = gp.q[depth & 1u], out = gp.q[(depth + 1u) & 1u];
-  const uint32_t total = gp.counts[depth];
+  const uint32_t total = gp.counts[depth * kQueueStride];
   const int d = (int)depth;
   for (;;) {
     uint32_t chunk = 0;
-    if (threadIdx.x == 0) chunk = atomicAdd(&gp.work[depth], 1u);
+    if (threadIdx.x == 0) chunk = atomicAdd(&gp.work[depth * kQueueStride], 1u);
     chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
     if ((uint64_t)chunk * kBlock >= total) break;
     const uint32_t e = chunk * kBlock + threadIdx.x;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_bounce_kernel
         }
       }
     }
-    const uint32_t slot = wave_append(&gp.counts[depth + 1u], alive);
+    const uint32_t slot = wave_append(&gp.counts[(depth + 1u) * kQueueStride], alive);
     if (alive) {
       out.o[slot] = make_float4(epos.x, epos.y, epos.z, fx);
       out.d[slot] = make_float4(ndir.x, ndir.y, ndir.z, ndir.w);
