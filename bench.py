@@ -160,6 +160,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    shadow_walk = -1
     kernel_ms = 0.0
     render_ms = 0.0     # lt_render_kernel alone (kernel_ms also holds the running-mean kernel behind each fused launch)
     launches = 0
@@ -167,6 +168,7 @@ def main():
         step(d)
         # the per-call HIP events sit on the launch stream; reading them waits for this step's kernels only
         s = r.stats()
+        shadow_walk = s["shadow_packets"]
         kernel_ms += s["kernel_ms"]
         render_ms += s["render_ms"]
         launches += s["kernel_launches"]
@@ -210,7 +212,9 @@ def main():
                        "triangles": scene.n_prims, "bvh_nodes": scene.n_nodes, "width": W, "height": H, "spp": args.spp,
                        "rays_per_frame": rays_total, "node_visits_per_ray": nodes_total / rays_total,
                        "tri_tests_per_ray": tris_total / rays_total, "kernel_only_mrays_per_s": round(rays_total * args.steps / kernel_s / 1e6, 2),
-                       "frame_ms": round(ms_per_step, 3)},
+                       "frame_ms": round(ms_per_step, 3),
+                       # which of its two (pixel-identical) walks the library timed faster for this scene's shadow rays
+                       "shadow_ray_walk": {1: "any-hit packets", 0: "per lane"}.get(shadow_walk, "not timed")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic("%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program)) if world == 1 else None,

@@ -127,7 +127,8 @@ typedef struct lt_hip_stats {
   float kernel_ms;              /* HIP-event time over the kernels of the last call, on the call's stream */
   float total_ms;               /* lt_hip_render only: upload + kernels + read-back wall time */
   float render_ms;              /* kernel_ms without the running-mean kernels that follow fused multi-sample launches */
-  uint32_t reserved;
+  int32_t shadow_packets;       /* how the last call walked its shadow rays: 1 = any-hit packets, 0 = per lane (chosen per scene
+                                 * and program by timing both once; LT_SHADOW_PACKETS=0/1 forces), -1 = not timed yet */
 } lt_hip_stats;
 
 int lt_hip_abi_version(void);

@@ -40,7 +40,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("rays", ctypes.c_uint64), ("shadow_rays", ctypes.c_uint64), ("node_visits", ctypes.c_uint64),
                 ("tri_tests", ctypes.c_uint64), ("pixels", ctypes.c_uint64), ("frames", ctypes.c_uint32),
                 ("kernel_launches", ctypes.c_uint32), ("kernel_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-                ("render_ms", ctypes.c_float), ("reserved", ctypes.c_uint32)]
+                ("render_ms", ctypes.c_float), ("shadow_packets", ctypes.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

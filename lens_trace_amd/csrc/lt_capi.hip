@@ -104,6 +104,8 @@ struct lt_hip_context {
   unsigned long long* d_stats = nullptr;
   uint32_t* d_queues = nullptr;      // persistent mode: 8 per-XCD work counters per launch of a call
   uint32_t queue_frames = 0;
+  int shadow_mode[6] = {-1, -1, -1, -1, -1, -1};   // per built-in program: shadow rays as any-hit packets (1) or per lane (0); -1 = not timed yet
+  hipEvent_t cal_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float* d_samples = nullptr;        // un-accumulated sample images of a fused multi-sample launch
   uint64_t d_samples_bytes = 0;
   uint32_t* d_order = nullptr;       // persistent mode: hand-out order of the squares (slow-path squares first), cached
@@ -200,6 +202,7 @@ extern "C" int lt_hip_destroy(lt_hip_context* ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (hipEvent_t e : ctx->mean_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->cal_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return LT_OK;
@@ -406,6 +409,7 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
   ctx->n_mats = n_mats;
   ctx->bvh_height = height;
   ctx->has_scene = true;
+  for (int& m : ctx->shadow_mode) m = -1;
   return LT_OK;
 }
 
@@ -756,6 +760,13 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   sc.mats = (const Material*)ctx->d_mats;
   sc.lights = (const Lights*)ctx->d_lights;
   sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_mats = ctx->n_mats;
+  // Shadow rays as any-hit packets or per lane (traverse_packet_pairs_anyhit, lt_device.hpp): +20 % or -37 % of a frame
+  // depending on the scene, so each (scene, program) is timed once, on the first launch that can be repeated without
+  // changing the result, and the faster walk kept.  LT_SHADOW_PACKETS=0/1 forces one (tests, A/B measurements).
+  const char* spe = getenv("LT_SHADOW_PACKETS");
+  const bool hasShadowRays = !userProgram && d->program != LT_PROGRAM_BASIC && d->program != LT_PROGRAM_CUSTOM_OPENCL;
+  int shadowMode = spe ? (atoi(spe) != 0) : (hasShadowRays ? ctx->shadow_mode[d->program] : 0);
+  sc.shadowPackets = shadowMode > 0 ? 1u : 0u;
 
   FrameParams fp{};
   fp.camx = cam[0]; fp.camy = cam[1]; fp.camz = cam[2];
@@ -833,7 +844,9 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       uint32_t lds = (uint32_t)std::max(1, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
       if (giWavefront) {
-        const int grc = launch_gi_sets(ctx, s, sc, fp, lc, lds, giPixels, gi25Sets ? samplesPerSet : 0u, p.floats, out_launch, out_device, launches);
+        SceneDev scGi = sc;
+        scGi.shadowPackets = spe ? sc.shadowPackets : 0u;   // the pipeline's bounce stages cast incoherent shadow rays: per lane
+        const int grc = launch_gi_sets(ctx, s, scGi, fp, lc, lds, giPixels, gi25Sets ? samplesPerSet : 0u, p.floats, out_launch, out_device, launches);
         if (grc) return grc;
         launches--;   // (counted again below)
       } else if (userProgram) {
@@ -842,13 +855,36 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         float* outPtr = out_launch;
         void* args[] = {(void*)&sc, (void*)&fp, (void*)&outPtr, (void*)&statsPtr, (void*)&queues};
         LT_HIP_CHECK(ctx, hipModuleLaunchKernel(deep ? up.deep : up.lds, grid.x, 1, 1, kBlock, 1, 1, lds, s, args, nullptr));
-      } else switch (d->program) {
+      } else {
+        // time both shadow-ray walks once per (scene, program): only on a launch that can run twice (it overwrites its output)
+        const bool calibrate = shadowMode < 0 && persistent && !stats && ctx->bvh_height <= kLdsStack && fp.accumulateN < 0;
+        for (int pass = 0; pass < (calibrate ? 2 : 1); pass++) {
+          if (calibrate) {
+            for (hipEvent_t& e : ctx->cal_ev) if (!e) LT_HIP_CHECK(ctx, hipEventCreate(&e));
+            sc.shadowPackets = (uint32_t)pass;
+            if (pass == 1) LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
+            LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass], s));
+          }
+          switch (d->program) {
         case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
         case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
         case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
         case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
         case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
         default: launch_program<kCustom>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
+          }
+          if (calibrate) LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass + 1], s));
+        }
+        if (calibrate) {
+          float perLane = 0.0f, packets = 0.0f;
+          LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->cal_ev[3]));
+          LT_HIP_CHECK(ctx, hipEventElapsedTime(&perLane, ctx->cal_ev[0], ctx->cal_ev[1]));
+          LT_HIP_CHECK(ctx, hipEventElapsedTime(&packets, ctx->cal_ev[2], ctx->cal_ev[3]));
+          shadowMode = packets < 0.97f * perLane ? 1 : 0;   // (a tie keeps the per-lane walk)
+          ctx->shadow_mode[d->program] = shadowMode;
+          sc.shadowPackets = (uint32_t)shadowMode;
+          launches++;
+        }
       }
       LT_HIP_CHECK(ctx, hipGetLastError());
       launches++;
@@ -862,6 +898,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   ctx->last = lt_hip_stats{};
   ctx->last.frames = frames;
   ctx->last.kernel_launches = launches;
+  ctx->last.shadow_packets = shadowMode;
   // pixels actually inside the image for this call's tiles
   uint64_t px = 0;
   for (uint32_t k = 0; k < p.tilesInCall; k++) {

@@ -59,6 +59,7 @@ struct SceneDev {
   const Material* mats;
   const Lights* lights;
   uint32_t n_nodes, n_prims, n_mats;
+  uint32_t shadowPackets;   // != 0: shadow rays of the non-counting kernels walk as any-hit packets (chosen per scene by the host)
 };
 
 struct Counters {
@@ -557,6 +558,78 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
   }
 }
 
+// Any-hit packet walk over the child-pair records for shadow rays (non-counting kernels): their callers read only hitType
+// (acc.cl:276, gi.cl:295,:351), so neither the order of the walk nor which occluder is found matters.  The wave walks the
+// union of its rays' node sets, left child first; a lane drops out at its first accepted triangle; the walk ends when the
+// stack is empty or no lane is left.  Whether this beats 64 independent per-lane walks depends on how coherent a scene's
+// shadow rays are -- 8x8 neighbouring surface points looking at one small light: +15 % of the whole frame on the 1 M-triangle
+// wall; a large light close to curved geometry, or surface points scattered in depth: -41 % (blob in a box), -32 % (triangle
+// soup) -- so the host times both on a scene's first frame and sets SceneDev::shadowPackets (lt_capi.hip).
+template <int PROGRAM>
+__device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl,
+                                                    int* ldsWave) {
+  using u64 = unsigned long long;
+  const ConstF4 nodes = (ConstF4)(unsigned long long)sc.nodes;
+  const ConstF4 pairs = (ConstF4)(unsigned long long)sc.pairs;
+  const ConstF4 tris = (ConstF4)(unsigned long long)sc.tris;
+  const int lane = (int)__lane_id();
+  const u64 all = __builtin_amdgcn_ballot_w64(true);
+  const int leader = __ffsll((long long)all) - 1;
+  bool open = true;   // this lane still looks for an occluder
+  auto leaf_test = [&](uint32_t off, u64 m) {
+    if (((m >> lane) & 1ull) && open && (int)off != ign) {
+      const ConstF4 t = tris + 3 * (size_t)off;
+      const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
+      if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl)) {
+        pl.prim = (int)off;
+        pl.hitType = 1;
+        open = false;
+      }
+    }
+  };
+  u64 mask;
+  uint32_t cur = 0u;
+  {
+    const F8v nd = *(ConstF8)(nodes);
+    mask = __builtin_amdgcn_ballot_w64(box_test_finite(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz));
+    if (mask == 0ull) return;
+    const uint32_t meta = __float_as_uint(nd.s7);
+    if ((meta & 0xffffu) != 0u) { leaf_test(__float_as_uint(nd.s6), mask); return; }
+  }
+  int sp = 0;
+  for (;;) {
+    const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+    const F16v pr = *(ConstF16)(pairs + 4 * (size_t)ci);
+    const u64 hmL = __builtin_amdgcn_ballot_w64(open && box_test_finite(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz)) & mask;
+    const u64 hmR = __builtin_amdgcn_ballot_w64(open && box_test_finite(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz)) & mask;
+    const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
+    const bool leafL = (__float_as_uint(pr.s7) & 0xffffu) != 0u, leafR = (__float_as_uint(pr.sf) & 0xffffu) != 0u;
+    if (hmL != 0ull && leafL) leaf_test(refL, hmL);
+    if (hmR != 0ull && leafR) leaf_test(refR, hmR);
+    if (__builtin_amdgcn_ballot_w64(open) == 0ull) return;
+    const bool goL = hmL != 0ull && !leafL, goR = hmR != 0ull && !leafR;
+    if (goL && goR) {   // the right child waits
+      if (lane == leader) {
+        ldsWave[sp * kBlock + 0] = (int)refR;
+        ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmR;
+        ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmR >> 32);
+      }
+      sp++;
+    }
+    if (goL) {
+      cur = refL; mask = hmL;
+    } else if (goR) {
+      cur = refR; mask = hmR;
+    } else {
+      if (sp == 0) return;
+      sp--;
+      cur = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 0]);
+      mask = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 1]) |
+             ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 2]) << 32);
+    }
+  }
+}
+
 // Camera rays: packet traversal when the wave qualifies, the per-lane traversal otherwise.
 template <int PROGRAM, bool DEEP, bool STATS>
 __device__ inline void traverse_camera(const SceneDev& sc, const Ray& ray, Hit& pl, Stack<DEEP>& st, Counters& c) {
@@ -607,6 +680,10 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
                       __builtin_fabsf(iz) < __builtin_inff() && __builtin_fabsf(ray.o.x) < __builtin_inff() &&
                       __builtin_fabsf(ray.o.y) < __builtin_inff() && __builtin_fabsf(ray.o.z) < __builtin_inff();
   if (__all(finite)) {
+    if (ANYHIT && !DEEP && sc.shadowPackets != 0u) {
+      traverse_packet_pairs_anyhit<PROGRAM>(sc, ray, ix, iy, iz, useIgnore ? ignore : -1, pl, st.lds - __lane_id());
+      return;
+    }
     traverse_nodes_impl<PROGRAM, DEEP, STATS, true, ANYHIT>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
   } else {   // e.g. the image-centre column/row, where a direction component is exactly 0
     traverse_nodes_impl<PROGRAM, DEEP, STATS, false, ANYHIT>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);

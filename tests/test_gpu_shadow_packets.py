@@ -1,0 +1,87 @@
+"""GPU tests (-m gpu) of the two walks for shadow rays: 64 independent per-lane walks, or one any-hit packet walk per
+wavefront (traverse_packet_pairs_anyhit).  The callers of a shadow ray read only whether it hit, so both give the same
+pixels; which is faster depends on the scene, and the library times both once per (scene, program)."""
+import os
+
+import numpy as np
+import pytest
+
+from lens_trace_amd import scene as sc
+from lens_trace_amd import synth
+from lens_trace_amd.renderer import KERNEL_MODE_TILE, RendererHIP, RenderPropertiesHIP
+from oracle import pyoracle as po
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+PATHS = {"accumulator": "examples/accumulator/resources/kernels/accumulator.cl",
+         "basic_lighting": "resources/kernels/opencl/basic_lighting.cl",
+         "global_illumination": "examples/global_illumination/resources/kernels/global_illumination.cl",
+         "global_illumination25": "resources/kernels/opencl/global_illumination.cl"}
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    r = RendererHIP(0)
+    yield r
+    r.close()
+
+
+def scenes():
+    yield "cornell", sc.load_ltsb(os.path.join(GOLDEN, "cornell_box_O0.ltsb")).validate()
+    yield "lens", sc.load_ltsb(os.path.join(GOLDEN, "cornell_box_lens_O0.ltsb")).validate() if os.path.exists(
+        os.path.join(GOLDEN, "cornell_box_lens_O0.ltsb")) else synth.blob_in_box(subdiv=2).validate()
+    yield "wall", synth.heightfield_wall(48).validate()
+    yield "soup", synth.triangle_soup(3000).validate()
+    yield "blob", synth.blob_in_box(subdiv=3).validate()
+
+
+@pytest.mark.parametrize("name,scene", list(scenes()), ids=lambda v: v if isinstance(v, str) else "")
+@pytest.mark.parametrize("forced", ["0", "1"], ids=["per-lane", "packets"])
+def test_both_walks_match_the_oracle(renderer, monkeypatch, forced, name, scene):
+    monkeypatch.setenv("LT_SHADOW_PACKETS", forced)
+    cam = sc.camera_with_frame(scene.camera, 3)
+    for prog, W, H, kw in (("accumulator", 96, 64, {}), ("accumulator", 33, 17, {"kernelMode": KERNEL_MODE_TILE}),
+                           ("global_illumination", 48, 40, {"giMaxDepth": 5}), ("basic_lighting", 24, 16, {}),
+                           ("global_illumination25", 16, 12, {"giMaxDepth": 3})):
+        for gi_path in (("1",) if not prog.startswith("global") else ("0", "1")):
+            monkeypatch.setenv("LT_GI_MEGAKERNEL", gi_path)
+            out = np.full((H, W, 3), np.nan, dtype=np.float32)
+            renderer.render(RenderPropertiesHIP(PATHS[prog], (W, H, 3), out, scene, pCamera=cam, **kw))
+            assert renderer.stats()["shadow_packets"] == int(forced)
+            want = po.render(scene, cam, W, H, po.PROGRAMS[prog], kw.get("kernelMode", 0), gi_max_depth=kw.get("giMaxDepth", 16))
+            assert np.array_equal(out, want), (name, prog, W, H, gi_path)
+
+
+def test_the_walk_is_timed_once_per_scene_and_program(monkeypatch):
+    monkeypatch.delenv("LT_SHADOW_PACKETS", raising=False)
+    monkeypatch.setenv("LT_GI_MEGAKERNEL", "1")
+    r = RendererHIP(0)
+    scene = synth.heightfield_wall(64).validate()
+    W, H = 320, 200
+    want = po.render(scene, sc.camera_with_frame(scene.camera, 1), W, H, po.ACCUMULATOR)
+
+    def once(path, **kw):
+        out = np.full((H, W, 3), np.nan, dtype=np.float32)
+        r.render(RenderPropertiesHIP(path, (W, H, 3), out, scene, pCamera=sc.camera_with_frame(scene.camera, 1), **kw))
+        return out, r.stats()
+
+    out, st = once(PATHS["accumulator"])
+    assert st["kernel_launches"] == 2 and st["shadow_packets"] in (0, 1)       # first launch repeated with the other walk
+    assert np.array_equal(out, want)
+    chosen = st["shadow_packets"]
+    out, st = once(PATHS["accumulator"])
+    assert st["kernel_launches"] == 1 and st["shadow_packets"] == chosen
+    assert np.array_equal(out, want)
+    out, st = once(PATHS["accumulator"], frameFirst=1, frameCount=3, accumulate=True)
+    assert st["kernel_launches"] == 1 and st["shadow_packets"] == chosen          # known: the fused launch is not repeated
+    out, st = once("resources/kernels/opencl/basic.cl")
+    assert st["kernel_launches"] == 1 and st["shadow_packets"] == 0               # no shadow rays: nothing to time
+    out, st = once(PATHS["basic_lighting"])
+    assert st["kernel_launches"] == 2                                             # its own decision
+    r.set_scene(synth.heightfield_wall(32).validate())                            # a new scene forgets the decisions
+    scene = synth.heightfield_wall(32).validate()
+    out, st = once(PATHS["accumulator"], frameFirst=1, frameCount=4, accumulate=True)
+    assert st["kernel_launches"] == 2                                             # timed on the (repeatable) fused launch
+    out2, st = once(PATHS["accumulator"], frameFirst=1, frameCount=4, accumulate=True)
+    assert st["kernel_launches"] == 1 and np.array_equal(out, out2)
+    r.close()
