@@ -565,7 +565,7 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
 // shadow rays are -- 8x8 neighbouring surface points looking at one small light: +15 % of the whole frame on the 1 M-triangle
 // wall; a large light close to curved geometry, or surface points scattered in depth: -41 % (blob in a box), -32 % (triangle
 // soup) -- so the host times both on a scene's first frame and sets SceneDev::shadowPackets (lt_capi.hip).
-template <int PROGRAM>
+template <int PROGRAM, int NEG = -1>   // NEG >= 0: all rays of the wave share the direction-sign octant NEG (box_test_signed)
 __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl,
                                                     int* ldsWave) {
   using u64 = unsigned long long;
@@ -600,8 +600,10 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
   for (;;) {
     const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
     const F16v pr = *(ConstF16)(pairs + 4 * (size_t)ci);
-    const u64 hmL = __builtin_amdgcn_ballot_w64(open && box_test_finite(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz)) & mask;
-    const u64 hmR = __builtin_amdgcn_ballot_w64(open && box_test_finite(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz)) & mask;
+    const u64 hmL = __builtin_amdgcn_ballot_w64(open && (NEG >= 0 ? box_test_signed<(NEG >= 0 ? NEG : 0)>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz)
+                                                                         : box_test_finite(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz))) & mask;
+    const u64 hmR = __builtin_amdgcn_ballot_w64(open && (NEG >= 0 ? box_test_signed<(NEG >= 0 ? NEG : 0)>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz)
+                                                                         : box_test_finite(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz))) & mask;
     const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
     const bool leafL = (__float_as_uint(pr.s7) & 0xffffu) != 0u, leafR = (__float_as_uint(pr.sf) & 0xffffu) != 0u;
     if (hmL != 0ull && leafL) leaf_test(refL, hmL);
@@ -681,7 +683,25 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
                       __builtin_fabsf(ray.o.y) < __builtin_inff() && __builtin_fabsf(ray.o.z) < __builtin_inff();
   if (__all(finite)) {
     if (ANYHIT && !DEEP && sc.shadowPackets != 0u) {
-      traverse_packet_pairs_anyhit<PROGRAM>(sc, ray, ix, iy, iz, useIgnore ? ignore : -1, pl, st.lds - __lane_id());
+      int* const row = st.lds - __lane_id();
+      const int ign = useIgnore ? ignore : -1;
+#ifndef LT_NO_SHADOW_OCTANTS   // (waves whose shadow rays share their direction signs: slab test without min / max, +1.9 % on the wall)
+      const unsigned long long all = __builtin_amdgcn_ballot_w64(true), bx = __builtin_amdgcn_ballot_w64(ix < 0.0f),
+                               by = __builtin_amdgcn_ballot_w64(iy < 0.0f), bz = __builtin_amdgcn_ballot_w64(iz < 0.0f);
+      if ((bx == 0ull || bx == all) && (by == 0ull || by == all) && (bz == 0ull || bz == all)) {
+        switch ((bx != 0ull ? 1 : 0) | (by != 0ull ? 2 : 0) | (bz != 0ull ? 4 : 0)) {
+          case 0: traverse_packet_pairs_anyhit<PROGRAM, 0>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 1: traverse_packet_pairs_anyhit<PROGRAM, 1>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 2: traverse_packet_pairs_anyhit<PROGRAM, 2>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 3: traverse_packet_pairs_anyhit<PROGRAM, 3>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 4: traverse_packet_pairs_anyhit<PROGRAM, 4>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 5: traverse_packet_pairs_anyhit<PROGRAM, 5>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 6: traverse_packet_pairs_anyhit<PROGRAM, 6>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          default: traverse_packet_pairs_anyhit<PROGRAM, 7>(sc, ray, ix, iy, iz, ign, pl, row); return;
+        }
+      }
+#endif
+      traverse_packet_pairs_anyhit<PROGRAM>(sc, ray, ix, iy, iz, ign, pl, row);
       return;
     }
     traverse_nodes_impl<PROGRAM, DEEP, STATS, true, ANYHIT>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
