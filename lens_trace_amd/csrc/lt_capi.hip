@@ -29,8 +29,9 @@ __global__ void lt_retile_kernel(const float* __restrict__ prims, float4* __rest
   tris[3 * (size_t)i + 2] = make_float4(p[8] - az, 0.0f, 0.0f, 0.0f);
 }
 
-// Child-pair records for the packet walk (traverse_packet_pairs): pairs[i] = (record of node i + 1, record of node
-// secondChildOffset(i)) for every interior node i, an interior child's `offset` field replaced by that child's own index.
+// Child-pair records for the packet walks (traverse_packet_pairs, traverse_packet_pairs_anyhit): pairs[i] = (record of node
+// i + 1, record of node secondChildOffset(i)) for every interior node i, each child's `offset` field replaced by what the walks
+// put on their stack: index | axis << 29 for an interior child, 0x80000000 | primitive offset for a leaf.
 // Leaves get no record (their slot stays unwritten and is never read).
 __global__ void lt_pair_kernel(const float4* __restrict__ nodes, float4* __restrict__ pairs, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -41,7 +42,9 @@ __global__ void lt_pair_kernel(const float4* __restrict__ nodes, float4* __restr
   for (int k = 0; k < 2; k++) {
     const float4 ca = nodes[2 * (size_t)child[k]];
     float4 cb = nodes[2 * (size_t)child[k] + 1];
-    if ((__float_as_uint(cb.w) & 0xffffu) == 0u) cb.z = __uint_as_float(child[k]);
+    const uint32_t cmeta = __float_as_uint(cb.w);
+    cb.z = __uint_as_float((cmeta & 0xffffu) == 0u ? (child[k] | (((cmeta >> 16) & 3u) << 29))      // interior: index | axis << 29
+                                                    : (0x80000000u | __float_as_uint(cb.z)));        // leaf: tagged primitive offset
     pairs[4 * (size_t)i + 2 * k] = ca;
     pairs[4 * (size_t)i + 2 * k + 1] = cb;
   }

@@ -501,23 +501,23 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
   for (;;) {
     const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));
     const uint32_t axis = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur >> 29));
-    const F16v pr = *(ConstF16)(pairs + 4 * (size_t)ci);
+    const F16v pr = *(ConstF16)((const __attribute__((address_space(4))) char*)pairs + (ci << 6));   // (32-bit byte offset: < 4 GiB of records)
     const u64 hmL = __builtin_amdgcn_ballot_w64(box_test_signed<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz)) & mask;
     const u64 hmR = __builtin_amdgcn_ballot_w64(box_test_signed<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz)) & mask;
     // everything below is wave-uniform; integer selects on values the compiler can see are scalar (a select between two of
     // the loaded floats, or on a bool it cannot prove uniform, becomes v_cndmask + readfirstlane)
     const bool neg = ((negBitsU >> axis) & 1u) != 0u;
     const u64 hmN = neg ? hmR : hmL, hmF = neg ? hmL : hmR;
+    // the records' `offset` fields come ready to use (lt_pair_kernel): a leaf as 0x80000000 | primitive offset, an interior
+    // child as index | axis << 29 -- what goes on the stack and into `cur` as is
     const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
-    const uint32_t metaL = __float_as_uint(pr.s7), metaR = __float_as_uint(pr.sf);
     const uint32_t refN = neg ? refR : refL, refF = neg ? refL : refR;
-    const uint32_t metaN = neg ? metaR : metaL, metaF = neg ? metaL : metaR;
-    const bool leafN = (metaN & 0xffffu) != 0u, leafF = (metaF & 0xffffu) != 0u;
-    const uint32_t entF = leafF ? (kLeafTag | refF) : (refF | (((metaF >> 16) & 3u) << 29));
+    const bool leafN = (int)refN < 0, leafF = (int)refF < 0;
+    const uint32_t entF = refF;
     bool haveNext = false;
     if (hmN != 0ull) {
       if (leafN) {
-        leaf_test(refN, hmN);
+        leaf_test(refN & 0x7fffffffu, hmN);
       } else {
         if (hmF != 0ull) {   // the far child waits for the near subtree
           if (lane == leader) {
@@ -527,14 +527,14 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
           }
           sp++;
         }
-        cur = refN | (((metaN >> 16) & 3u) << 29);
+        cur = refN;
         mask = hmN;
         continue;
       }
     }
     if (hmF != 0ull) {   // (the near child was missed, or was a leaf and is done)
       if (leafF) {
-        leaf_test(refF, hmF);
+        leaf_test(refF & 0x7fffffffu, hmF);
       } else {
         cur = entF;
         mask = hmF;
@@ -598,17 +598,19 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
   }
   int sp = 0;
   for (;;) {
-    const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-    const F16v pr = *(ConstF16)(pairs + 4 * (size_t)ci);
+    const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));   // (the axis bits are not needed here)
+    const F16v pr = *(ConstF16)((const __attribute__((address_space(4))) char*)pairs + (ci << 6));
     const u64 hmL = __builtin_amdgcn_ballot_w64(open && (NEG >= 0 ? box_test_signed<(NEG >= 0 ? NEG : 0)>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz)
                                                                          : box_test_finite(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz))) & mask;
     const u64 hmR = __builtin_amdgcn_ballot_w64(open && (NEG >= 0 ? box_test_signed<(NEG >= 0 ? NEG : 0)>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz)
                                                                          : box_test_finite(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz))) & mask;
     const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
-    const bool leafL = (__float_as_uint(pr.s7) & 0xffffu) != 0u, leafR = (__float_as_uint(pr.sf) & 0xffffu) != 0u;
-    if (hmL != 0ull && leafL) leaf_test(refL, hmL);
-    if (hmR != 0ull && leafR) leaf_test(refR, hmR);
-    if (__builtin_amdgcn_ballot_w64(open) == 0ull) return;
+    const bool leafL = (int)refL < 0, leafR = (int)refR < 0;   // (lt_pair_kernel tags leaves: 0x80000000 | primitive offset)
+    if ((hmL != 0ull && leafL) || (hmR != 0ull && leafR)) {
+      if (hmL != 0ull && leafL) leaf_test(refL & 0x7fffffffu, hmL);
+      if (hmR != 0ull && leafR) leaf_test(refR & 0x7fffffffu, hmR);
+      if (__builtin_amdgcn_ballot_w64(open) == 0ull) return;   // every lane has its occluder
+    }
     const bool goL = hmL != 0ull && !leafL, goR = hmR != 0ull && !leafR;
     if (goL && goR) {   // the right child waits
       if (lane == leader) {

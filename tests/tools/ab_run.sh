@@ -16,9 +16,9 @@ done
 rm -f gpurun_out/ab_*.npy
 for s in wall blob soup; do
   for rep in 1 2; do
-    python bench.py --scene $s --no-cpu-baseline --steps 3 | cut -c1-1200 > gpurun_out/bench_base_${s}_$rep.log 2>&1
+    python bench.py --scene $s --no-cpu-baseline --steps 3 > gpurun_out/bench_base_${s}_$rep.log 2>&1
     for t in "$@"; do
-      LT_HIP_LIBRARY=$PWD/lens_trace_amd/lib/v_$t.so python bench.py --scene $s --no-cpu-baseline --steps 3 | cut -c1-1200 > gpurun_out/bench_${t}_${s}_$rep.log 2>&1
+      LT_HIP_LIBRARY=$PWD/lens_trace_amd/lib/v_$t.so python bench.py --scene $s --no-cpu-baseline --steps 3 > gpurun_out/bench_${t}_${s}_$rep.log 2>&1
     done
   done
 done
