@@ -268,19 +268,31 @@ __device__ __forceinline__ bool box_test_finite(float lox, float loy, float loz,
   return tEnter <= tExit && tExit > 0.0f;
 }
 
-// box_test_finite for a ray whose direction signs are known at compile time (NEG bit a = direction component a is negative):
-// the entry plane of an axis is then the box's max (negative direction) or min, no v_min / v_max needed.  Same predicate:
-// (bound - o) * inv is monotonic in bound, so the selected product IS the min (or max) of the two, up to the sign of a zero,
-// which neither max3 / min3 nor the two compares can tell apart.
-template <int NEG>
-__device__ __forceinline__ bool box_test_signed(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray& ray,
-                                                float ix, float iy, float iz) {
-  const float nearX = (NEG & 1) ? hix : lox, farX = (NEG & 1) ? lox : hix;
-  const float nearY = (NEG & 2) ? hiy : loy, farY = (NEG & 2) ? loy : hiy;
-  const float nearZ = (NEG & 4) ? hiz : loz, farZ = (NEG & 4) ? loz : hiz;
-  const float tEnter = __builtin_fmaxf(__builtin_fmaxf((nearX - ray.o.x) * ix, (nearY - ray.o.y) * iy), (nearZ - ray.o.z) * iz);
-  const float tExit = __builtin_fminf(__builtin_fminf((farX - ray.o.x) * ix, (farY - ray.o.y) * iy), (farZ - ray.o.z) * iz);
-  return tEnter <= tExit && tExit > 0.0f;
+// Slab test as a wave-wide lane mask, for the packet walks.  NEG >= 0: the direction signs of every ray of the wave are known at
+// compile time (bit a = component a negative), so the entry plane of an axis is simply the box's max (negative direction) or
+// min and no v_min / v_max is needed -- same predicate as box_test_finite: (bound - o) * inv is monotonic in bound, so the
+// selected product IS the min (or max) of the two, up to the sign of a zero, which neither max3 / min3 nor the compares can
+// tell apart.  NEG < 0: signs unknown, box_test_finite's min / max form.
+// The wave's lane mask of a slab test, as the AND of the two compares' masks: `ballot(a && b)` makes the compiler
+// materialise the bool in a VGPR and compare it again (two vector instructions per test); two ballots and a scalar AND do not.
+template <int NEG>   // NEG < 0: signs unknown (box_test_finite's min / max form)
+__device__ __forceinline__ unsigned long long box_mask(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray& ray,
+                                                       float ix, float iy, float iz) {
+  float tEnter, tExit;
+  if (NEG >= 0) {
+    const float nearX = (NEG & 1) ? hix : lox, farX = (NEG & 1) ? lox : hix;
+    const float nearY = (NEG & 2) ? hiy : loy, farY = (NEG & 2) ? loy : hiy;
+    const float nearZ = (NEG & 4) ? hiz : loz, farZ = (NEG & 4) ? loz : hiz;
+    tEnter = __builtin_fmaxf(__builtin_fmaxf((nearX - ray.o.x) * ix, (nearY - ray.o.y) * iy), (nearZ - ray.o.z) * iz);
+    tExit = __builtin_fminf(__builtin_fminf((farX - ray.o.x) * ix, (farY - ray.o.y) * iy), (farZ - ray.o.z) * iz);
+  } else {
+    const float tx0 = (lox - ray.o.x) * ix, tx1 = (hix - ray.o.x) * ix;
+    const float ty0 = (loy - ray.o.y) * iy, ty1 = (hiy - ray.o.y) * iy;
+    const float tz0 = (loz - ray.o.z) * iz, tz1 = (hiz - ray.o.z) * iz;
+    tEnter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)), __builtin_fminf(tz0, tz1));
+    tExit = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fmaxf(tz0, tz1));
+  }
+  return __builtin_amdgcn_ballot_w64(tEnter <= tExit) & __builtin_amdgcn_ballot_w64(tExit > 0.0f);
 }
 
 template <bool FINITE>
@@ -465,7 +477,7 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
 // reference's: the near child's subtree (or leaf) completely before the far child's; a far child that must wait goes on
 // the wave-uniform stack with the mask of the lanes that hit it (a leaf as 0x80000000 | primitive offset).
 // NEG is the direction-sign octant the wave's rays share (bit a = component a negative; traverse_camera switches on it): with
-// the signs known at compile time the slab test picks each axis' entry plane directly (box_test_signed).
+// the signs known at compile time the slab test picks each axis' entry plane directly (box_mask<NEG>).
 template <int PROGRAM, int NEG>
 __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, Hit& pl, int* ldsWave) {
   using u64 = unsigned long long;
@@ -491,7 +503,7 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
   uint32_t cur;   // interior node: index | axis << 29
   {
     const F8v nd = *(ConstF8)(nodes);
-    mask = __builtin_amdgcn_ballot_w64(box_test_signed<NEG>(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz));
+    mask = box_mask<NEG>(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz);
     if (mask == 0ull) return;
     const uint32_t meta = __float_as_uint(nd.s7);
     if ((meta & 0xffffu) != 0u) { leaf_test(__float_as_uint(nd.s6), mask); return; }
@@ -502,8 +514,8 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
     const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));
     const uint32_t axis = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur >> 29));
     const F16v pr = *(ConstF16)((const __attribute__((address_space(4))) char*)pairs + (ci << 6));   // (32-bit byte offset: < 4 GiB of records)
-    const u64 hmL = __builtin_amdgcn_ballot_w64(box_test_signed<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz)) & mask;
-    const u64 hmR = __builtin_amdgcn_ballot_w64(box_test_signed<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz)) & mask;
+    const u64 hmL = box_mask<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz) & mask;
+    const u64 hmR = box_mask<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz) & mask;
     // everything below is wave-uniform; integer selects on values the compiler can see are scalar (a select between two of
     // the loaded floats, or on a bool it cannot prove uniform, becomes v_cndmask + readfirstlane)
     const bool neg = ((negBitsU >> axis) & 1u) != 0u;
@@ -565,7 +577,7 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
 // shadow rays are -- 8x8 neighbouring surface points looking at one small light: +15 % of the whole frame on the 1 M-triangle
 // wall; a large light close to curved geometry, or surface points scattered in depth: -41 % (blob in a box), -32 % (triangle
 // soup) -- so the host times both on a scene's first frame and sets SceneDev::shadowPackets (lt_capi.hip).
-template <int PROGRAM, int NEG = -1>   // NEG >= 0: all rays of the wave share the direction-sign octant NEG (box_test_signed)
+template <int PROGRAM, int NEG = -1>   // NEG >= 0: all rays of the wave share the direction-sign octant NEG (box_mask<NEG>)
 __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl,
                                                     int* ldsWave) {
   using u64 = unsigned long long;
@@ -591,25 +603,25 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
   uint32_t cur = 0u;
   {
     const F8v nd = *(ConstF8)(nodes);
-    mask = __builtin_amdgcn_ballot_w64(box_test_finite(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz));
+    mask = box_mask<NEG>(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz);
     if (mask == 0ull) return;
     const uint32_t meta = __float_as_uint(nd.s7);
     if ((meta & 0xffffu) != 0u) { leaf_test(__float_as_uint(nd.s6), mask); return; }
   }
   int sp = 0;
+  u64 openMask = all;   // lanes still looking for an occluder
   for (;;) {
     const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));   // (the axis bits are not needed here)
     const F16v pr = *(ConstF16)((const __attribute__((address_space(4))) char*)pairs + (ci << 6));
-    const u64 hmL = __builtin_amdgcn_ballot_w64(open && (NEG >= 0 ? box_test_signed<(NEG >= 0 ? NEG : 0)>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz)
-                                                                         : box_test_finite(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz))) & mask;
-    const u64 hmR = __builtin_amdgcn_ballot_w64(open && (NEG >= 0 ? box_test_signed<(NEG >= 0 ? NEG : 0)>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz)
-                                                                         : box_test_finite(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz))) & mask;
+    const u64 hmL = box_mask<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz) & mask & openMask;
+    const u64 hmR = box_mask<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz) & mask & openMask;
     const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
     const bool leafL = (int)refL < 0, leafR = (int)refR < 0;   // (lt_pair_kernel tags leaves: 0x80000000 | primitive offset)
     if ((hmL != 0ull && leafL) || (hmR != 0ull && leafR)) {
       if (hmL != 0ull && leafL) leaf_test(refL & 0x7fffffffu, hmL);
       if (hmR != 0ull && leafR) leaf_test(refR & 0x7fffffffu, hmR);
-      if (__builtin_amdgcn_ballot_w64(open) == 0ull) return;   // every lane has its occluder
+      openMask = __builtin_amdgcn_ballot_w64(open);
+      if (openMask == 0ull) return;   // every lane has its occluder
     }
     const bool goL = hmL != 0ull && !leafL, goR = hmR != 0ull && !leafR;
     if (goL && goR) {   // the right child waits
