@@ -767,7 +767,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   // depending on the scene, so each (scene, program) is timed once, on the first launch that can be repeated without
   // changing the result, and the faster walk kept.  LT_SHADOW_PACKETS=0/1 forces one (tests, A/B measurements).
   const char* spe = getenv("LT_SHADOW_PACKETS");
-  const bool hasShadowRays = !userProgram && d->program != LT_PROGRAM_BASIC && d->program != LT_PROGRAM_CUSTOM_OPENCL;
+  const bool hasShadowRays = d->program == LT_PROGRAM_ACCUMULATOR || d->program == LT_PROGRAM_BASIC_LIGHTING;   // (the GI programs' kernels hold the per-lane walk only)
   int shadowMode = spe ? (atoi(spe) != 0) : (hasShadowRays ? ctx->shadow_mode[d->program] : 0);
   sc.shadowPackets = shadowMode > 0 ? 1u : 0u;
 
@@ -864,7 +864,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         for (int pass = 0; pass < (calibrate ? 2 : 1); pass++) {
           if (calibrate) {
             for (hipEvent_t& e : ctx->cal_ev) if (!e) LT_HIP_CHECK(ctx, hipEventCreate(&e));
-            sc.shadowPackets = (uint32_t)pass;
+            sc.shadowPackets = pass == 0 ? 1u : 0u;   // packets first: the cold first launch of a scene counts against them
             if (pass == 1) LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
             LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass], s));
           }
@@ -881,8 +881,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         if (calibrate) {
           float perLane = 0.0f, packets = 0.0f;
           LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->cal_ev[3]));
-          LT_HIP_CHECK(ctx, hipEventElapsedTime(&perLane, ctx->cal_ev[0], ctx->cal_ev[1]));
-          LT_HIP_CHECK(ctx, hipEventElapsedTime(&packets, ctx->cal_ev[2], ctx->cal_ev[3]));
+          LT_HIP_CHECK(ctx, hipEventElapsedTime(&packets, ctx->cal_ev[0], ctx->cal_ev[1]));
+          LT_HIP_CHECK(ctx, hipEventElapsedTime(&perLane, ctx->cal_ev[2], ctx->cal_ev[3]));
           shadowMode = packets < 0.97f * perLane ? 1 : 0;   // (a tie keeps the per-lane walk)
           ctx->shadow_mode[d->program] = shadowMode;
           sc.shadowPackets = (uint32_t)shadowMode;

@@ -696,7 +696,9 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
                       __builtin_fabsf(iz) < __builtin_inff() && __builtin_fabsf(ray.o.x) < __builtin_inff() &&
                       __builtin_fabsf(ray.o.y) < __builtin_inff() && __builtin_fabsf(ray.o.z) < __builtin_inff();
   if (__all(finite)) {
-    if (ANYHIT && !DEEP && sc.shadowPackets != 0u) {
+    // (not in the global-illumination programs: most of their shadow rays start at bounce hits and are incoherent, and the
+    // extra walks cost their register-heavy kernels a third of their speed on small scenes)
+    if (ANYHIT && !DEEP && PROGRAM != kGI && PROGRAM != kGI25 && sc.shadowPackets != 0u) {
       int* const row = st.lds - __lane_id();
       const int ign = useIgnore ? ignore : -1;
 #ifndef LT_NO_SHADOW_OCTANTS   // (waves whose shadow rays share their direction signs: slab test without min / max, +1.9 % on the wall)
