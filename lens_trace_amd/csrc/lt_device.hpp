@@ -516,43 +516,44 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
     const F16v pr = *(ConstF16)((const __attribute__((address_space(4))) char*)pairs + (ci << 6));   // (32-bit byte offset: < 4 GiB of records)
     const u64 hmL = box_mask<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz) & mask;
     const u64 hmR = box_mask<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz) & mask;
-    // everything below is wave-uniform; integer selects on values the compiler can see are scalar (a select between two of
-    // the loaded floats, or on a bool it cannot prove uniform, becomes v_cndmask + readfirstlane)
-    const bool neg = ((negBitsU >> axis) & 1u) != 0u;
-    const u64 hmN = neg ? hmR : hmL, hmF = neg ? hmL : hmR;
-    // the records' `offset` fields come ready to use (lt_pair_kernel): a leaf as 0x80000000 | primitive offset, an interior
-    // child as index | axis << 29 -- what goes on the stack and into `cur` as is
+    // everything below is wave-uniform.  One scalar branch on dirIsNeg[axis] and the rest written out for each order costs
+    // fewer scalar instructions than selecting near / far for six values (the scalar unit is what limits this loop)
     const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
-    const uint32_t refN = neg ? refR : refL, refF = neg ? refL : refR;
-    const bool leafN = (int)refN < 0, leafF = (int)refF < 0;
-    const uint32_t entF = refF;
     bool haveNext = false;
-    if (hmN != 0ull) {
-      if (leafN) {
-        leaf_test(refN & 0x7fffffffu, hmN);
-      } else {
-        if (hmF != 0ull) {   // the far child waits for the near subtree
-          if (lane == leader) {
-            ldsWave[sp * kBlock + 0] = (int)entF;
-            ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmF;
-            ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmF >> 32);
+    // the records' `offset` fields come ready to use (lt_pair_kernel): a leaf as 0x80000000 | primitive offset, an interior
+    // child as index | axis << 29 -- what goes on the stack and into `cur` as is.  Returns true when `cur` / `mask` hold the
+    // next interior node.
+    auto visit = [&](u64 hmN, u64 hmF, uint32_t refN, uint32_t refF) -> bool {
+      if (hmN != 0ull) {
+        if ((int)refN < 0) {
+          leaf_test(refN & 0x7fffffffu, hmN);
+        } else {
+          if (hmF != 0ull) {   // the far child waits for the near subtree
+            if (lane == leader) {
+              ldsWave[sp * kBlock + 0] = (int)refF;
+              ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmF;
+              ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmF >> 32);
+            }
+            sp++;
           }
-          sp++;
+          cur = refN;
+          mask = hmN;
+          return true;
         }
-        cur = refN;
-        mask = hmN;
-        continue;
       }
-    }
-    if (hmF != 0ull) {   // (the near child was missed, or was a leaf and is done)
-      if (leafF) {
-        leaf_test(refF & 0x7fffffffu, hmF);
-      } else {
-        cur = entF;
-        mask = hmF;
-        haveNext = true;
+      if (hmF != 0ull) {   // (the near child was missed, or was a leaf and is done)
+        if ((int)refF < 0) {
+          leaf_test(refF & 0x7fffffffu, hmF);
+        } else {
+          cur = refF;
+          mask = hmF;
+          return true;
+        }
       }
-    }
+      return false;
+    };
+    if (((negBitsU >> axis) & 1u) != 0u) haveNext = visit(hmR, hmL, refR, refL);
+    else haveNext = visit(hmL, hmR, refL, refR);
     while (!haveNext) {
       if (sp == 0) return;
       sp--;
@@ -588,6 +589,7 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
   const u64 all = __builtin_amdgcn_ballot_w64(true);
   const int leader = __ffsll((long long)all) - 1;
   bool open = true;   // this lane still looks for an occluder
+  u64 openMask = all; // ... and the wave's mask of such lanes
   auto leaf_test = [&](uint32_t off, u64 m) {
     if (((m >> lane) & 1ull) && open && (int)off != ign) {
       const ConstF4 t = tris + 3 * (size_t)off;
@@ -598,6 +600,7 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
         open = false;
       }
     }
+    openMask = __builtin_amdgcn_ballot_w64(open);
   };
   u64 mask;
   uint32_t cur = 0u;
@@ -609,40 +612,48 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
     if ((meta & 0xffffu) != 0u) { leaf_test(__float_as_uint(nd.s6), mask); return; }
   }
   int sp = 0;
-  u64 openMask = all;   // lanes still looking for an occluder
   for (;;) {
     const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));   // (the axis bits are not needed here)
     const F16v pr = *(ConstF16)((const __attribute__((address_space(4))) char*)pairs + (ci << 6));
     const u64 hmL = box_mask<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz) & mask & openMask;
     const u64 hmR = box_mask<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz) & mask & openMask;
     const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
-    const bool leafL = (int)refL < 0, leafR = (int)refR < 0;   // (lt_pair_kernel tags leaves: 0x80000000 | primitive offset)
-    if ((hmL != 0ull && leafL) || (hmR != 0ull && leafR)) {
-      if (hmL != 0ull && leafL) leaf_test(refL & 0x7fffffffu, hmL);
-      if (hmR != 0ull && leafR) leaf_test(refR & 0x7fffffffu, hmR);
-      openMask = __builtin_amdgcn_ballot_w64(open);
-      if (openMask == 0ull) return;   // every lane has its occluder
-    }
-    const bool goL = hmL != 0ull && !leafL, goR = hmR != 0ull && !leafR;
-    if (goL && goR) {   // the right child waits
-      if (lane == leader) {
-        ldsWave[sp * kBlock + 0] = (int)refR;
-        ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmR;
-        ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmR >> 32);
+    // (lt_pair_kernel tags leaves: 0x80000000 | primitive offset; plain nested ifs keep the control flow on SCC branches)
+    if (hmL != 0ull) {
+      if ((int)refL < 0) {
+        leaf_test(refL & 0x7fffffffu, hmL);
+      } else {
+        if (hmR != 0ull) {
+          if ((int)refR < 0) {
+            leaf_test(refR & 0x7fffffffu, hmR);
+            if (openMask == 0ull) return;
+          } else {   // the right child waits
+            if (lane == leader) {
+              ldsWave[sp * kBlock + 0] = (int)refR;
+              ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmR;
+              ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmR >> 32);
+            }
+            sp++;
+          }
+        }
+        cur = refL; mask = hmL;
+        continue;
       }
-      sp++;
     }
-    if (goL) {
-      cur = refL; mask = hmL;
-    } else if (goR) {
-      cur = refR; mask = hmR;
-    } else {
-      if (sp == 0) return;
-      sp--;
-      cur = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 0]);
-      mask = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 1]) |
-             ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 2]) << 32);
+    if (hmR != 0ull) {
+      if ((int)refR < 0) {
+        leaf_test(refR & 0x7fffffffu, hmR);
+      } else {
+        if (openMask == 0ull) return;
+        cur = refR; mask = hmR;
+        continue;
+      }
     }
+    if (openMask == 0ull || sp == 0) return;   // every lane has its occluder, or nothing is left to visit
+    sp--;
+    cur = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 0]);
+    mask = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 1]) |
+           ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 2]) << 32);
   }
 }
 
