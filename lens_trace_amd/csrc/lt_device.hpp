@@ -486,8 +486,6 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
   const ConstF4 pairs = (ConstF4)(unsigned long long)sc.pairs;
   const ConstF4 tris = (ConstF4)(unsigned long long)sc.tris;
   const int lane = (int)__lane_id();
-  const u64 all = __builtin_amdgcn_ballot_w64(true);
-  const int leader = __ffsll((long long)all) - 1;
   constexpr uint32_t negBitsU = (uint32_t)NEG;   // the direction signs the whole wave shares, a compile-time constant here
   auto leaf_test = [&](uint32_t off, u64 m) {
     if ((m >> lane) & 1ull) {
@@ -529,11 +527,10 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
           leaf_test(refN & 0x7fffffffu, hmN);
         } else {
           if (hmF != 0ull) {   // the far child waits for the near subtree
-            if (lane == leader) {
-              ldsWave[sp * kBlock + 0] = (int)refF;
-              ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmF;
-              ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmF >> 32);
-            }
+            // (every active lane stores the same three dwords at the same address: no exec juggling for a "leader")
+            ldsWave[sp * kBlock + 0] = (int)refF;
+            ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmF;
+            ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmF >> 32);
             sp++;
           }
           cur = refN;
@@ -587,7 +584,6 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
   const ConstF4 tris = (ConstF4)(unsigned long long)sc.tris;
   const int lane = (int)__lane_id();
   const u64 all = __builtin_amdgcn_ballot_w64(true);
-  const int leader = __ffsll((long long)all) - 1;
   bool open = true;   // this lane still looks for an occluder
   u64 openMask = all; // ... and the wave's mask of such lanes
   auto leaf_test = [&](uint32_t off, u64 m) {
@@ -615,8 +611,9 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
   for (;;) {
     const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));   // (the axis bits are not needed here)
     const F16v pr = *(ConstF16)((const __attribute__((address_space(4))) char*)pairs + (ci << 6));
-    const u64 hmL = box_mask<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz) & mask & openMask;
-    const u64 hmR = box_mask<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz) & mask & openMask;
+    const u64 live = mask & openMask;
+    const u64 hmL = box_mask<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz) & live;
+    const u64 hmR = box_mask<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz) & live;
     const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
     // (lt_pair_kernel tags leaves: 0x80000000 | primitive offset; plain nested ifs keep the control flow on SCC branches)
     if (hmL != 0ull) {
@@ -628,11 +625,9 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
             leaf_test(refR & 0x7fffffffu, hmR);
             if (openMask == 0ull) return;
           } else {   // the right child waits
-            if (lane == leader) {
-              ldsWave[sp * kBlock + 0] = (int)refR;
-              ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmR;
-              ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmR >> 32);
-            }
+            ldsWave[sp * kBlock + 0] = (int)refR;
+            ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmR;
+            ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmR >> 32);
             sp++;
           }
         }
