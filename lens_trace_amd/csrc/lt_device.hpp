@@ -302,8 +302,9 @@ __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float 
                 : box_test_reference(lox, loy, loz, hix, hiy, hiz, ray, ix, iy, iz, nx, ny, nz);
 }
 
-// One node per iteration, as few instructions as possible (since launches stopped being dominated by their slowest
-// wavefront -- several samples per launch, lt_capi.hip -- the loop is bound by vector-instruction issue: VALU busy 97 %):
+// The per-lane walk (bounce rays; shadow rays where a scene's are incoherent; camera rays of the few waves that cannot form a
+// packet).  One node per iteration, as few instructions as possible: since launches stopped being dominated by their slowest
+// wavefront (several samples per launch, lt_capi.hip) it is bound by occupancy times instructions on the node-to-node chain:
 //  * a leaf found in iteration i is only *noted* (`pend`); its triangle is fetched and tested at the top of iteration i+1,
 //    right behind the issue of the next node's loads, so both latencies overlap (testing it inside iteration i costs 25 %).
 //    Exact: the reference's traversal never reads the payload (no clipping against payload.t, acc.cl:113-130), and a lane
@@ -408,6 +409,8 @@ typedef float F16v __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) F16v* ConstF16;
 __device__ __forceinline__ float4 ld_const(ConstF4 p) { const F4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 
+// (This one-node-per-iteration form serves the counting kernels, whose work counters must be the reference's per lane; the
+// other kernels use traverse_packet_pairs below.)
 template <int PROGRAM, bool STATS>
 __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool nxU, bool nyU, bool nzU,
                                        Hit& pl, int* ldsWave, Counters& c) {
