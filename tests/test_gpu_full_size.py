@@ -111,6 +111,21 @@ def test_bench_partition_of_the_16_sample_frame_reassembles_exactly(renderer, wa
     assert np.array_equal(image.cpu().numpy(), whole)
 
 
+def test_shadow_ray_walks_agree_on_the_full_frame(renderer, wall, monkeypatch):
+    """The any-hit packet walk and the per-lane walk for shadow rays (the library picks one per scene by timing) give the same
+    4K frame, with a rotated camera too (mixed direction signs inside wavefronts)."""
+    for yaw in (0.0, 0.4):
+        cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, 3)
+        frames = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("LT_SHADOW_PACKETS", mode)
+            out = np.empty((H, W, 3), dtype=np.float32)
+            renderer.render(RenderPropertiesHIP(ACC, (W, H, 3), out, wall, pCamera=cam, frameFirst=3, frameCount=2, accumulate=True))
+            assert renderer.stats()["shadow_packets"] == int(mode)
+            frames[mode] = out
+        assert np.array_equal(frames["0"], frames["1"])
+
+
 def test_running_mean_of_16_frames_equals_folding_single_frames(renderer, wall):
     got = np.empty((H, W, 3), dtype=np.float32)
     renderer.render(RenderPropertiesHIP(ACC, (W, H, 3), got, wall, pCamera=wall.camera, frameFirst=1, frameCount=16, accumulate=True))
