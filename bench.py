@@ -11,13 +11,25 @@ A "step" is one complete frame of the workload: all 16 sample launches of this r
 and the root-side untile.  Timed region: barrier + synchronize, K steps, synchronize + barrier; MAX over ranks.
 Scene and framebuffers are resident in HBM before the timed region starts.  Rank 0 prints one JSON line.
 
-`roofline` prices the dominant kernel (one sample launch of lt_render_kernel) against HBM: achieved = ALGORITHMIC
-bytes per launch / average launch duration (HIP events on the launch stream, taken inside the timed region);
-algorithmic bytes = 32 B x node visits + 76 B x triangle tests + 36 B x pixels (12 B written + 24 B running-mean
-read-modify-write), SURVEY.md section 8(d) -- node visits / triangle tests are the reference algorithm's counts,
-measured once with device atomics (and equal to the CPU oracle's counters, see tests).
+`roofline` describes the dominant kernel (lt_render_kernel: one launch renders all samples of a step).  The kernel is not
+HBM-bound -- the 1 M-triangle scene (250 MB with the derived arrays) lives in the 256 MB Infinity Cache and the eight L2s, and
+the packet walks fetch a node once per wavefront through the scalar cache -- so the bound it is priced against is the busiest
+instruction-issue pipe, from the rocprofv3 PMC passes of this same command (tools/collect_profiles.sh ->
+profiles/<round>/issue_profile.json): `achieved` = that pipe's instructions per launch (a property of the workload and the
+build) / its units / (the launch time measured LIVE here with HIP events x the profiled shader clock), `peak` = the pipe's issue
+rate (MI355X_MICROARCH.md: wave64 VALU 0.5 instructions per SIMD-cycle; one scalar instruction per CU-cycle), `frac` <= 1.
+Beside it: `traffic` = measured HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), `hbm_measured_gbs` / `hbm_measured_frac`
+against the 8 TB/s peak, and `algorithmic_gbs` = SURVEY section 8(d)'s bytes (32 B x node visits + 76 B x triangle tests +
+36 B x pixel-samples, the REFERENCE algorithm's counts, measured once with device atomics and equal to the CPU oracle's) per
+launch / launch time -- several times the HBM peak, which is what "on_chip_reuse_factor" states.
 `cpu_baseline` is the CPU oracle (a C restatement of the reference kernels, kind "port") on this host's cores over
-one bounded sample of the same workload; it is a reported baseline, not a target."""
+one bounded sample of the same workload; it is a reported baseline, not a target.
+
+Math flavour: the library's default -- bit-identical to the reference's OpenCL kernels compiled for gfx950 with
+-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt ("strict"; tests/test_gpu_reference_kernels.py,
+tests/test_gpu_full_size.py compare the whole 4K frame).  The reference itself passes NULL build options
+(src/opencl/renderer_opencl.cpp:50), under which the OpenCL compiler may contract a*b+c as it sees fit; against that build
+the stochastic programs differ in a few pixels per image (reported by the same test file)."""
 import argparse
 import json
 import os
@@ -31,21 +43,59 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
-def measured_traffic(workload_key):
-    """HBM bytes per launch of the dominant kernel from the PMC counters: they cannot be read from inside this process,
-    so tools/collect_profiles.sh collects FETCH_SIZE / WRITE_SIZE for this same command in separate rocprofv3 passes
-    and the summary is committed as profiles/<round>/hbm_traffic.json.  Returned only when it was measured on the same
-    workload; otherwise None."""
+def _latest_profile(name, workload_key):
+    """profiles/r*/<name> of the newest round whose `workload` is this run's (PMC counters cannot be read from inside this
+    process: tools/collect_profiles.sh collects them for this same command in separate rocprofv3 passes)."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name))):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
         if d.get("workload", "").startswith(workload_key):
-            best = d.get("hbm_bytes_per_launch")
+            best = d
+            best["_file"] = os.path.relpath(f, ROOT)
     return best
+
+
+def measured_traffic(workload_key):
+    d = _latest_profile("hbm_traffic.json", workload_key)
+    return d.get("hbm_bytes_per_launch") if d else None
+
+
+def roofline(workload_key, kernel_name, launch_ms, launches_per_step, spp, alg_bytes_per_launch, single_gpu):
+    """See the module docstring."""
+    alg_gbs = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    traffic = measured_traffic(workload_key) if single_gpu else None
+    prof = _latest_profile("issue_profile.json", workload_key) if single_gpu else None
+    out = {"kernel": kernel_name, "launch_ms": round(launch_ms, 4), "launches_per_step": launches_per_step,
+           "samples_per_launch": spp / launches_per_step, "traffic": traffic,
+           "algorithmic_bytes_per_launch": alg_bytes_per_launch, "algorithmic_gbs": round(alg_gbs, 1)}
+    if traffic:
+        hbm = traffic / (launch_ms * 1e-3) / 1e9
+        out.update({"hbm_measured_gbs": round(hbm, 1), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_measured_frac": round(hbm / HBM_PEAK_GBS, 4),
+                    "on_chip_reuse_factor": round(alg_bytes_per_launch / traffic, 1)})
+    raw = (prof or {}).get("raw", {})
+    clock = (prof or {}).get("effective_clock_ghz")
+    if prof and clock and "SQ_INSTS_VALU" in raw and "SQ_INSTS_SALU" in raw:
+        cycles = launch_ms * 1e-3 * clock * 1e9          # live launch time x the shader clock the profiled launch held
+        pipes = {"valu-issue": (raw["SQ_INSTS_VALU"] / 1024.0 / cycles, 0.5, "wave-instructions per SIMD-cycle"),
+                 "scalar-issue": ((raw["SQ_INSTS_SALU"] + raw.get("SQ_INSTS_SMEM", 0.0)) / 256.0 / cycles, 1.0, "instructions per CU-cycle")}
+        name = max(pipes, key=lambda k: pipes[k][0] / pipes[k][1])
+        ach, peak, unit = pipes[name]
+        out = dict({"bound": name, "achieved": round(ach, 4), "peak": peak, "unit": unit, "frac": round(ach / peak, 4)}, **out)
+        out["pipes"] = {k: round(v[0] / v[1], 4) for k, v in pipes.items()}
+        split = prof.get("wave_cycle_split") or {}
+        out["wave_cycle_split"] = {k.split(" ")[0]: (round(v, 4) if v is not None else None) for k, v in split.items()}
+        out["shader_clock_ghz"] = round(clock, 3)
+        out["source"] = prof["_file"]
+    else:
+        # no counter profile of this workload in the tree: only the HBM side can be stated
+        hbm = (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None
+        out = dict({"bound": "hbm", "achieved": round(hbm, 1) if hbm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(hbm / HBM_PEAK_GBS, 4) if hbm else None}, **out)
+    return out
 
 
 def parse():
@@ -61,6 +111,7 @@ def parse():
     ap.add_argument("--program", default="accumulator")
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-soup", action="store_true", help="skip the second figure (config 4's incoherent triangle-soup variant)")
     return ap.parse_args()
 
 
@@ -78,8 +129,26 @@ def build_scene(args):
     return sc.load_ltsb(os.path.join(ROOT, "tests", "golden", "cornell_box_O0.ltsb")), "Cornell box (reference buffers)"
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: this process -- before it imports torch
+    or touches the GPU -- starts the N ranks as a fresh torch.distributed.run job (the command the driver uses), lets rank 0
+    print the JSON line on the shared stdout, and exits with the job's status.  (Child processes, never a re-exec.)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
     from lens_trace_amd import _capi as C
@@ -188,7 +257,6 @@ def main():
         launch_ms = render_ms / max(launches, 1)
         launches_per_step = max(launches, 1) / args.steps
         my_alg_bytes_per_launch = my_alg_bytes_per_step / launches_per_step
-        achieved = my_alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
         out = {
             # BASELINE.json's metric on its configuration; other --scene / --width / --height runs say what they ran
             "metric": "Mrays/s (primary+secondary+shadow), %s @%s" % (
@@ -204,25 +272,28 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "note": "shadow rays stop at the first accepted hit (their callers read only hitType): same pixels, fewer node visits than "
-                    "the reference algorithm, whose counts (measured once with the counting kernel) price roofline.achieved",
+            "note": "math flavour = the library default, bit-identical to the reference's OpenCL kernels built for gfx950 with "
+                    "-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt (the reference passes NULL options, under which the "
+                    "stochastic programs differ from this build in a few pixels per image: tests/test_gpu_reference_kernels.py); "
+                    "shadow rays stop at the first accepted hit (their callers read only hitType): same pixels, fewer node visits "
+                    "than the reference algorithm, whose counts (measured once with the counting kernel) price roofline.algorithmic_gbs",
             "config": {"workload": "%s, %d triangles, %dx%d, %d spp running mean, program %s, %s" % (
                            scene_name, scene.n_prims, W, H, args.spp, args.program,
                            "whole image on 1 GPU" if world == 1 else "%dx%d tiles interleaved over %d GPUs + 1 RCCL gather" % (plan.tile_w, plan.tile_h, world)),
+                       "workload_key": "%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program),   # (names the profiles/ summaries of this workload)
                        "triangles": scene.n_prims, "bvh_nodes": scene.n_nodes, "width": W, "height": H, "spp": args.spp,
                        "rays_per_frame": rays_total, "node_visits_per_ray": nodes_total / rays_total,
                        "tri_tests_per_ray": tris_total / rays_total, "kernel_only_mrays_per_s": round(rays_total * args.steps / kernel_s / 1e6, 2),
                        "frame_ms": round(ms_per_step, 3),
                        # which of its two (pixel-identical) walks the library timed faster for this scene's shadow rays
                        "shadow_ray_walk": {1: "any-hit packets", 0: "per lane"}.get(shadow_walk, "not timed")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic("%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program)) if world == 1 else None,
-                         "kernel": "lt_render_kernel<%s>" % args.program if launches_per_step <= args.spp else "wavefront GI pipeline (all its stage kernels)",
-                         "launch_ms": round(launch_ms, 4),
-                         "launches_per_step": launches_per_step, "samples_per_launch": args.spp / launches_per_step,
-                         "algorithmic_bytes_per_launch": my_alg_bytes_per_launch},
+            "roofline": roofline("%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program),
+                                 "lt_render_kernel<%s>" % args.program if launches_per_step <= args.spp else "wavefront GI pipeline (all its stage kernels)",
+                                 launch_ms, launches_per_step, args.spp, my_alg_bytes_per_launch, world == 1),
         }
+        if world == 1 and args.scene == "wall" and not args.no_soup:
+            # the headline scene is the coherent one; the same kernel on config 4's seeded triangle-soup variant beside it
+            out["config"].update(soup_figure(args, r, program, dev, stream))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, scene, program)
         print(json.dumps(out), flush=True)
@@ -230,6 +301,37 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     r.close()
+
+
+def soup_figure(args, r, program, dev, stream):
+    """Config 4's incoherent variant (seeded triangle soup, same triangle count, resolution, program and samples):
+    Mrays/s of a few whole steps on this GPU, rays counted by the counting kernel."""
+    import torch
+    from lens_trace_amd import synth
+    from lens_trace_amd.renderer import make_desc
+    soup = synth.triangle_soup(2 * args.cells * args.cells).validate()
+    r.set_scene(soup)
+    W, H, D = args.width, args.height, 3
+
+    def desc(stats=False):
+        return make_desc(program, W, H, D, soup.camera, frame_first=1, frame_count=args.spp, accumulate=True, accumulate_base=0, stats=stats)
+    buf = torch.zeros(r.output_floats(desc()), dtype=torch.float32, device=dev)
+    r.render_device(desc(True), buf.data_ptr(), buf.numel() * 4, stream)
+    torch.cuda.synchronize()
+    st = r.stats()
+    for _ in range(2):     # allocates scratch, times the two shadow-ray walks once, warms up
+        r.render_device(desc(), buf.data_ptr(), buf.numel() * 4, stream)
+    torch.cuda.synchronize()
+    steps = max(2, min(args.steps, 5))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.render_device(desc(), buf.data_ptr(), buf.numel() * 4, stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    walk = r.stats()["shadow_packets"]
+    return {"soup_mrays_per_s": round(st["rays"] * steps / dt / 1e6, 2), "soup_frame_ms": round(dt / steps * 1e3, 3),
+            "soup_triangles": soup.n_prims, "soup_node_visits_per_ray": st["node_visits"] / st["rays"],
+            "soup_shadow_ray_walk": {1: "any-hit packets", 0: "per lane"}.get(walk, "not timed")}
 
 
 def cpu_baseline(args, scene, program):

@@ -31,7 +31,8 @@ enum StructureType {
   STRUCTURE_TYPE_ACCELERATION_STRUCTURE_PROPERTIES,
   STRUCTURE_TYPE_RENDER_PROPERTIES_HIP,
   STRUCTURE_TYPE_THREAD_ORGANIZATION_HIP,
-  STRUCTURE_TYPE_PROGRESSIVE_PROPERTIES_HIP
+  STRUCTURE_TYPE_PROGRESSIVE_PROPERTIES_HIP,
+  STRUCTURE_TYPE_BACKEND_PROPERTIES_HIP
 };
 enum RenderPlatform { RENDER_PLATFORM_OPENCL, RENDER_PLATFORM_CUDA, RENDER_PLATFORM_OPTIX, RENDER_PLATFORM_HIP };
 enum KernelMode { KERNEL_MODE_LINEAR, KERNEL_MODE_TILE };

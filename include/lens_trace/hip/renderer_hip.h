@@ -26,6 +26,21 @@ struct ProgressivePropertiesHIP {
   int32_t giMaxDepth;           // 0 = the reference's 16
 };
 
+// Optional extension, chained through pNext like the one above (in any order).
+struct BackendPropertiesHIP {
+  StructureType sType;          // STRUCTURE_TYPE_BACKEND_PROPERTIES_HIP
+  void* pNext;
+  // 0 (default): rsqrt / sqrt / sinf / cosf / clamp as ROCm's OpenCL device library gives them to the reference kernels on
+  // this GPU -- render() is bit-identical to RendererOpenCL running the same kernel file on the MI355X.  1: the correctly
+  // rounded forms every IEEE machine reproduces (what the CPU oracle computes; LT_RENDER_FLAG_PORTABLE_MATH).
+  uint32_t portableMath;
+  // Scene-change contract.  0 (default): every render() hashes the four scene buffers in full and re-uploads when anything
+  // changed -- the reference's "upload on every call" semantics (renderer_opencl.cpp:107-120) at the price of one pass over
+  // host memory (~20 ms for the 1 M-triangle scene).  != 0: the caller versions its scene -- the buffers are re-examined only
+  // when the pointers, sizes or this number differ from the previous call's.
+  uint64_t sceneVersion;
+};
+
 struct RenderPropertiesHIP {
   StructureType sType;          // STRUCTURE_TYPE_RENDER_PROPERTIES_HIP
   void* pNext;
@@ -48,8 +63,8 @@ class RendererHIP final : public Renderer {
   ~RendererHIP();
   void render(void* pRenderProperties);
   bool isValid() const { return context != nullptr; }
-  // Scene buffers are uploaded once and reused while render() keeps receiving the same buffers (same addresses, sizes
-  // and content fingerprint).  Call this after modifying a scene buffer in place.
+  // Scene buffers stay resident while render() keeps receiving the same content (BackendPropertiesHIP::sceneVersion).
+  // Forces the next render() to upload again.
   void invalidateScene();
   const char* getLastError() const;
 
@@ -59,5 +74,5 @@ class RendererHIP final : public Renderer {
   // caller hands over different objects or buffers
   const void* cachedKey[4];
   uint64_t cachedSize[4];
-  uint64_t cachedFingerprint;
+  uint64_t cachedVersion;
 };

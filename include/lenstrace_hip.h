@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define LT_HIP_ABI_VERSION 2
+#define LT_HIP_ABI_VERSION 3
 
 typedef struct lt_hip_context lt_hip_context;
 
@@ -81,10 +81,16 @@ enum {
   LT_RENDER_FLAG_STATS = 1u,    /* count rays / node visits / triangle tests with device atomics (slower) */
   LT_RENDER_FLAG_PIXEL_COUNTERS = 2u,/* diagnostic (implies STATS, needs depth >= 4): instead of the colour, write each
                                         pixel's own {rays, shadow rays, node visits, triangle tests} as 4 floats */
-  LT_RENDER_FLAG_DEVICE_LIBM = 4u    /* use the GPU device library's rsqrt / sqrt / sinf / cosf / clamp exactly as ROCm's OpenCL
-                                        gives them to the reference kernels (v_rsq_f32, v_sqrt_f32, ocml trig, v_med3_f32)
-                                        instead of the portable correctly-rounded forms the CPU oracle reproduces: makes the
-                                        output bit-identical to the reference's OpenCL kernels on this GPU */
+  LT_RENDER_FLAG_DEVICE_LIBM = 4u,   /* accepted and ignored since ABI 3: it names what is now the default flavour (below) */
+  LT_RENDER_FLAG_PORTABLE_MATH = 8u  /* Floating-point flavour of four leaf functions ("Floating-point model").
+                                        DEFAULT (flag clear): rsqrt / sqrt / sinf / cosf / clamp exactly as ROCm's OpenCL device
+                                        library gives them to the reference kernels on this GPU (v_rsq_f32, v_sqrt_f32, ocml
+                                        trig, v_med3_f32) -- the output is bit-identical to the reference's own OpenCL kernels
+                                        compiled for gfx950 (tests/test_gpu_reference_kernels.py).
+                                        Flag set: correctly rounded forms every IEEE machine reproduces -- what the CPU oracle
+                                        computes; differs from the default by <= 1-2 ulp in those leaf functions, which the
+                                        stochastic programs' random() can amplify into a flipped ray decision in ~0.03 % of
+                                        pixels. */
 };
 
 typedef struct lt_hip_render_desc {
@@ -129,6 +135,8 @@ typedef struct lt_hip_stats {
   float render_ms;              /* kernel_ms without the running-mean kernels that follow fused multi-sample launches */
   int32_t shadow_packets;       /* how the last call walked its shadow rays: 1 = any-hit packets, 0 = per lane (chosen per scene
                                  * and program by timing both once; LT_SHADOW_PACKETS=0/1 forces), -1 = not timed yet */
+  uint32_t scene_uploads;       /* lt_hip_set_scene calls of this context that uploaded ... */
+  uint32_t scene_reused;        /* ... and those that found the resident scene's content unchanged (full hash) and kept it */
 } lt_hip_stats;
 
 int lt_hip_abi_version(void);
@@ -159,7 +167,9 @@ int lt_hip_program_from_path(const char* kernel_file_path, int* out_program);
 int lt_hip_resolve_program(lt_hip_context* ctx, const char* kernel_file_path, int* out_program);
 
 /* Uploads (host pointers) and validates the four scene buffers; keeps them resident until the next
- * set_scene / destroy.  Also builds the traversal-side triangle array (48-byte stride: A, B-A, C-A).  The BVH is
+ * set_scene / destroy.  A call whose four buffers have the sizes and the content (a hash of every byte) of the resident
+ * scene returns at once and keeps it: callers may pass their scene on every render, as the reference does
+ * (renderer_opencl.cpp:107-120), and in-place edits are honoured.  Also builds the traversal-side triangle array (48-byte stride: A, B-A, C-A).  The BVH is
  * traversed in the uploaded LinearBVHNode layout itself. */
 int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims,
                      uint64_t prim_bytes, const void* materials, uint64_t material_bytes, const void* lights,

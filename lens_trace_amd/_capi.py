@@ -16,7 +16,8 @@ PROGRAM_CUSTOM_OPENCL = 5
 KERNEL_MODE_LINEAR, KERNEL_MODE_TILE = 0, 1
 RENDER_FLAG_STATS = 1
 RENDER_FLAG_PIXEL_COUNTERS = 2
-RENDER_FLAG_DEVICE_LIBM = 4
+RENDER_FLAG_DEVICE_LIBM = 4      # ignored since ABI 3 (it is the default flavour)
+RENDER_FLAG_PORTABLE_MATH = 8
 
 # every symbol include/lenstrace_hip.h declares
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",
@@ -40,7 +41,8 @@ class Stats(ctypes.Structure):
     _fields_ = [("rays", ctypes.c_uint64), ("shadow_rays", ctypes.c_uint64), ("node_visits", ctypes.c_uint64),
                 ("tri_tests", ctypes.c_uint64), ("pixels", ctypes.c_uint64), ("frames", ctypes.c_uint32),
                 ("kernel_launches", ctypes.c_uint32), ("kernel_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-                ("render_ms", ctypes.c_float), ("shadow_packets", ctypes.c_int32)]
+                ("render_ms", ctypes.c_float), ("shadow_packets", ctypes.c_int32),
+                ("scene_uploads", ctypes.c_uint32), ("scene_reused", ctypes.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -91,7 +93,7 @@ def load():
     for name in EXPORTS:
         if name not in ("lt_hip_last_error",):
             getattr(L, name).restype = i32
-    if L.lt_hip_abi_version() != 2:
+    if L.lt_hip_abi_version() != 3:
         raise ImportError("liblenstrace-hip.so ABI version mismatch")
     _lib = L
     return L

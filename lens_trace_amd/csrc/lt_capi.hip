@@ -73,6 +73,7 @@ __global__ void lt_running_mean_kernel(const float* __restrict__ samples, uint32
                                        uint64_t floats, int32_t base, FrameParams fp, int checkPadding) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= floats) return;
+  if (i % fp.depth >= 3u) return;   // render_square / the GI resolve stage write channels 0..2 only; the others are the caller's
   if (checkPadding) {
     const uint64_t pix = i / fp.depth, perTile = (uint64_t)fp.tileW * fp.tileH;
     const uint32_t k = (uint32_t)(pix / perTile), rem = (uint32_t)(pix % perTile);
@@ -102,6 +103,8 @@ struct lt_hip_context {
   uint32_t n_nodes = 0, n_prims = 0, n_mats = 0;
   int bvh_height = 0;
   bool has_scene = false;
+  uint64_t scene_hash = 0, scene_sizes[4] = {0, 0, 0, 0};   // content hash + sizes of the resident scene (lt_hip_set_scene)
+  uint32_t scene_uploads = 0, scene_reused = 0;
   float* d_out = nullptr;            // staging output for lt_hip_render
   uint64_t d_out_bytes = 0;
   unsigned long long* d_stats = nullptr;
@@ -127,7 +130,7 @@ struct lt_hip_context {
   uint64_t gi_pixels = 0;
   uint32_t* d_giCtl = nullptr;
   // user programs (hipRTC), cached by path like the reference's programMap
-  struct UserProgram { hipModule_t module; hipFunction_t lds, deep; };
+  struct UserProgram { hipModule_t module; hipFunction_t lds, deep, ldsPortable, deepPortable; };
   std::vector<UserProgram> user_programs;
   std::map<std::string, int> user_program_ids;
 };
@@ -280,10 +283,9 @@ static int compile_user_program(lt_hip_context* ctx, const std::string& path, in
   std::string err;
   if (!g_hiprtc.load(err)) return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, err);
   const std::string src = "#define LT_USER_PROGRAM 1\n#include \"lt_kernel.hpp\"\n#line 1 \"" + path + "\"\n" + user.str() +
-      "\nextern \"C\" __global__ __launch_bounds__(64) void lt_user_kernel_lds(SceneDev sc, FrameParams fp, float* out, unsigned long long* stats, uint32_t* queues) {\n"
-      "  render_kernel_body<kUser, Config<false, false, false>>(sc, fp, out, stats, queues);\n}\n"
-      "extern \"C\" __global__ __launch_bounds__(64) void lt_user_kernel_deep(SceneDev sc, FrameParams fp, float* out, unsigned long long* stats, uint32_t* queues) {\n"
-      "  render_kernel_body<kUser, Config<true, false, false>>(sc, fp, out, stats, queues);\n}\n";
+      "\n#define LT_USER_KERNEL(name, DEEP, DEVLIBM) extern \"C\" __global__ __launch_bounds__(64) void name(SceneDev sc, FrameParams fp, float* out, unsigned long long* stats, uint32_t* queues) { render_kernel_body<kUser, Config<DEEP, false, DEVLIBM>>(sc, fp, out, stats, queues); }\n"
+      "LT_USER_KERNEL(lt_user_kernel_lds, false, true)\nLT_USER_KERNEL(lt_user_kernel_deep, true, true)\n"
+      "LT_USER_KERNEL(lt_user_kernel_lds_portable, false, false)\nLT_USER_KERNEL(lt_user_kernel_deep_portable, true, false)\n";
   void* prog = nullptr;
   if (g_hiprtc.createProgram(&prog, src.c_str(), "lt_user_program.hip", 0, nullptr, nullptr) != 0)
     return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "hiprtcCreateProgram failed");
@@ -310,6 +312,8 @@ static int compile_user_program(lt_hip_context* ctx, const std::string& path, in
   LT_HIP_CHECK(ctx, hipModuleLoadData(&up.module, code.data()));
   LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.lds, up.module, "lt_user_kernel_lds"));
   LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.deep, up.module, "lt_user_kernel_deep"));
+  LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.ldsPortable, up.module, "lt_user_kernel_lds_portable"));
+  LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.deepPortable, up.module, "lt_user_kernel_deep_portable"));
   ctx->user_programs.push_back(up);
   *out_program = LT_PROGRAM_USER_BASE + (int)ctx->user_programs.size() - 1;
   ctx->user_program_ids[path] = *out_program;
@@ -363,12 +367,42 @@ static int validate_scene(const uint8_t* nodes, uint32_t n_nodes, const uint8_t*
   for (uint32_t i = 0; i < n_nodes; i++) {
     if (depth[i] < 0) continue;   // unreachable node: harmless
     if (depth[i] > height) height = depth[i];
-    if (nd[i].cnt == 0) {
-      depth[i + 1] = depth[i] + 1;
-      depth[nd[i].off] = depth[i] + 1;
+    if (nd[i].cnt == 0) {   // (max: a malformed buffer may share a child between parents; the LDS stack is sized by this height)
+      depth[i + 1] = std::max(depth[i + 1], depth[i] + 1);
+      depth[nd[i].off] = std::max(depth[nd[i].off], depth[i] + 1);
     }
   }
   return height;
+}
+
+// 64-bit content hash of a host buffer, four independent multiply-rotate lanes over 32-byte blocks (memory-bound: the four
+// scene buffers of the 1 M-triangle scene, 140 MB, take ~15-20 ms).  Used to tell "the same scene again" from "a buffer was
+// edited in place" without an upload.
+static uint64_t hash_bytes(const void* data, uint64_t n, uint64_t seed) {
+  constexpr uint64_t K = 0x9E3779B97F4A7C15ull;
+  uint64_t h[4] = {seed ^ K, seed + 0xC2B2AE3D27D4EB4Full, seed ^ 0x165667B19E3779F9ull, seed + 0x27D4EB2F165667C5ull};
+  const uint8_t* b = (const uint8_t*)data;
+  auto block = [&](const uint8_t* q) {
+    uint64_t w[4];
+    memcpy(w, q, 32);
+    for (int k = 0; k < 4; k++) {
+      h[k] = (h[k] ^ w[k]) * K;
+      h[k] = (h[k] << 29) | (h[k] >> 35);
+    }
+  };
+  uint64_t i = 0;
+  for (; i + 32 <= n; i += 32) block(b + i);
+  if (i < n) {
+    uint8_t tail[32] = {0};
+    memcpy(tail, b + i, (size_t)(n - i));
+    block(tail);
+  }
+  uint64_t r = n * K;
+  for (int k = 0; k < 4; k++) {
+    r = (r ^ h[k]) * K;
+    r ^= r >> 32;
+  }
+  return r;
 }
 
 extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims,
@@ -381,6 +415,19 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
     return fail(ctx, LT_ERR_BAD_SCENE, "scene buffer sizes are not whole multiples of LinearBVHNode(32) / Primitive(76) / Material(32) / LightContainer(260)");
   if (node_bytes > 0xffffffffull || prim_bytes / 76 > 0x7fffffffull / 48) return fail(ctx, LT_ERR_BAD_SCENE, "scene too large for 32-bit byte offsets (4 GiB of nodes / 2 GiB of traversal triangles)");
   const uint32_t n_nodes = (uint32_t)(node_bytes / 32), n_prims = (uint32_t)(prim_bytes / 76), n_mats = (uint32_t)(material_bytes / 32);
+  // The reference uploads all buffers on every render() (renderer_opencl.cpp:107-120); here the resident copy is kept when the
+  // caller hands over the same content again: sizes and a hash of EVERY byte (so an in-place edit of any vertex, node or
+  // material is honoured).  LT_SCENE_ALWAYS_UPLOAD=1 turns the shortcut off.
+  const uint64_t sizes[4] = {node_bytes, prim_bytes, material_bytes, light_bytes};
+  uint64_t hash = 0;
+  {
+    const void* bufs[4] = {nodes, prims, materials, lights};
+    for (int k = 0; k < 4; k++) hash = hash_bytes(bufs[k], sizes[k], hash + (uint64_t)k);
+  }
+  if (ctx->has_scene && hash == ctx->scene_hash && memcmp(sizes, ctx->scene_sizes, sizeof(sizes)) == 0 && !getenv("LT_SCENE_ALWAYS_UPLOAD")) {
+    ctx->scene_reused++;
+    return LT_OK;
+  }
   std::string msg;
   const int height = validate_scene((const uint8_t*)nodes, n_nodes, (const uint8_t*)prims, n_prims, n_mats, (const uint8_t*)lights, msg);
   if (height < 0) return fail(ctx, LT_ERR_BAD_SCENE, msg);
@@ -412,6 +459,9 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
   ctx->n_mats = n_mats;
   ctx->bvh_height = height;
   ctx->has_scene = true;
+  ctx->scene_hash = hash;
+  memcpy(ctx->scene_sizes, sizes, sizeof(sizes));
+  ctx->scene_uploads++;
   for (int& m : ctx->shadow_mode) m = -1;
   return LT_OK;
 }
@@ -458,8 +508,9 @@ template <int PROGRAM>
 static void launch_program(const LaunchConfig& k, dim3 grid, uint32_t lds, hipStream_t s, const SceneDev& sc, const FrameParams& fp,
                            float* out, unsigned long long* st, uint32_t* queues) {
 #define LT_LAUNCH(D, S, M) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, Config<D, S, M>>), grid, dim3(kBlock), lds, s, sc, fp, out, st, queues)
-  if (k.devlibm) {          // verification flavour: no counters
-    if (k.deep) LT_LAUNCH(true, false, true); else LT_LAUNCH(false, false, true);
+  if (k.devlibm) {          // the default flavour: the OpenCL device library's leaf math (Math<true>)
+    if (k.deep) { if (k.stats) LT_LAUNCH(true, true, true); else LT_LAUNCH(true, false, true); }
+    else { if (k.stats) LT_LAUNCH(false, true, true); else LT_LAUNCH(false, false, true); }
   } else if (k.deep) {
     if (k.stats) LT_LAUNCH(true, true, false); else LT_LAUNCH(true, false, false);
   } else {
@@ -742,8 +793,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   if (userProgram ? (size_t)(d->program - LT_PROGRAM_USER_BASE) >= ctx->user_programs.size()
                   : (d->program < LT_PROGRAM_BASIC || d->program > LT_PROGRAM_CUSTOM_OPENCL))
     return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "unknown program");
-  if (userProgram && (d->flags & (LT_RENDER_FLAG_STATS | LT_RENDER_FLAG_PIXEL_COUNTERS | LT_RENDER_FLAG_DEVICE_LIBM)))
-    return fail(ctx, LT_ERR_INVALID_ARGUMENT, "user programs are compiled without the counting / device-libm variants");
+  if (userProgram && (d->flags & (LT_RENDER_FLAG_STATS | LT_RENDER_FLAG_PIXEL_COUNTERS)))
+    return fail(ctx, LT_ERR_INVALID_ARGUMENT, "user programs are compiled without the counting variants");
   if (d->kernel_mode != LT_KERNEL_MODE_LINEAR && d->kernel_mode != LT_KERNEL_MODE_TILE) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "unknown kernel mode");
   if (!out_device) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "output pointer is NULL");
   if (out_bytes < p.floats * sizeof(float)) return fail(ctx, LT_ERR_BUFFER_TOO_SMALL, "output buffer smaller than the image/tile stack");
@@ -789,8 +840,9 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   fp.pixelCounters = pixelCounters;
   const bool stats = pixelCounters || (d->flags & LT_RENDER_FLAG_STATS) != 0;
   const bool deep = ctx->bvh_height > kLdsStack;
-  const bool devlibm = (d->flags & LT_RENDER_FLAG_DEVICE_LIBM) != 0;
-  if (devlibm && stats) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "LT_RENDER_FLAG_DEVICE_LIBM cannot be combined with the counter flags");
+  // The default flavour is the one that is bit-identical to the reference's OpenCL kernels on this GPU (Math<true>);
+  // LT_RENDER_FLAG_PORTABLE_MATH asks for the correctly rounded leaf functions the CPU oracle reproduces.
+  const bool devlibm = (d->flags & LT_RENDER_FLAG_PORTABLE_MATH) == 0;
   const LaunchConfig lc{deep, stats, devlibm};
   const uint32_t frames = d->frame_count ? d->frame_count : 1;
   const uint64_t nblocks = (uint64_t)p.tilesInCall * fp.blocksPerTile;
@@ -857,7 +909,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         unsigned long long* statsPtr = ctx->d_stats;
         float* outPtr = out_launch;
         void* args[] = {(void*)&sc, (void*)&fp, (void*)&outPtr, (void*)&statsPtr, (void*)&queues};
-        LT_HIP_CHECK(ctx, hipModuleLaunchKernel(deep ? up.deep : up.lds, grid.x, 1, 1, kBlock, 1, 1, lds, s, args, nullptr));
+        const hipFunction_t fn = devlibm ? (deep ? up.deep : up.lds) : (deep ? up.deepPortable : up.ldsPortable);
+        LT_HIP_CHECK(ctx, hipModuleLaunchKernel(fn, grid.x, 1, 1, kBlock, 1, 1, lds, s, args, nullptr));
       } else {
         // time both shadow-ray walks once per (scene, program): only on a launch that can run twice (it overwrites its output)
         const bool calibrate = shadowMode < 0 && persistent && !stats && ctx->bvh_height <= kLdsStack && fp.accumulateN < 0;
@@ -1009,5 +1062,7 @@ extern "C" int lt_hip_get_stats(lt_hip_context* ctx, lt_hip_stats* out) {
   int rc = finish_pending(ctx);
   if (rc) return rc;
   *out = ctx->last;
+  out->scene_uploads = ctx->scene_uploads;
+  out->scene_reused = ctx->scene_reused;
   return LT_OK;
 }

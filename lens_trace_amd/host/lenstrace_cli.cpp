@@ -7,7 +7,7 @@
 //   output   { file_path }
 // with "RENDER_PLATFORM_HIP" as the platform (OPENCL / CUDA scene files are accepted too: their kernel_file_path selects the
 // built-in program by basename) and one optional extension object for the device-side progressive loop:
-//   hip { frame_first, frame_count, accumulate, gi_max_depth, device }
+//   hip { frame_first, frame_count, accumulate, gi_max_depth, device, portable_math }
 // Output: .jpg (the reference's format: ImageWriter, value*255 narrowed to 8 bits, quality 100; image_writer.cpp holds the
 // encoder), .pfm (float RGB, bottom-up as the format demands), .ppm (8-bit, same narrowing), .raw (the float buffer as is).
 // The JSON reader below is a ~100-line recursive-descent parser written for this file (objects, arrays, strings, numbers,
@@ -124,6 +124,7 @@ struct SceneConfig {   // defaults of the reference's SceneParser
   std::string outputPath = "output.jpg";
   uint32_t frameFirst = 0, frameCount = 0, accumulate = 0;
   int giMaxDepth = 0, device = 0;
+  bool portableMath = false;   // default: the reference kernels' own math on this GPU (BackendPropertiesHIP)
 };
 
 double num(const Json* j, double d) { return j && j->kind == Json::Number ? j->number : d; }
@@ -161,6 +162,7 @@ bool loadScene(const std::string& path, SceneConfig& c, std::string& error) {
     c.frameCount = (uint32_t)num(h->find("frame_count"), 0);
     if (const Json* v = h->find("accumulate")) c.accumulate = v->kind == Json::Bool ? v->boolean : (v->number != 0);
     c.giMaxDepth = (int)num(h->find("gi_max_depth"), 0);
+    if (const Json* v = h->find("portable_math")) c.portableMath = v->kind == Json::Bool ? v->boolean : (v->number != 0);
     c.device = (int)num(h->find("device"), 0);
   }
   if (c.modelPath.empty()) { error = "scene has no world.<name>.file_path"; return false; }
@@ -268,6 +270,13 @@ int main(int argc, const char** argv) {
     pp.accumulate = cfg.accumulate;
     pp.giMaxDepth = cfg.giMaxDepth;
     rp.pNext = &pp;
+  }
+  BackendPropertiesHIP bp = {};
+  if (cfg.portableMath) {
+    bp.sType = STRUCTURE_TYPE_BACKEND_PROPERTIES_HIP;
+    bp.portableMath = 1;
+    bp.pNext = rp.pNext;
+    rp.pNext = &bp;
   }
   renderer.render(&rp);
   return writeImage(cfg.outputPath, output.data(), W, H, D) ? 0 : 1;

@@ -9,30 +9,12 @@
 
 #include "lenstrace_hip.h"
 
-// 64-bit FNV-1a over the sizes and a strided sample of the four scene buffers: cheap (a few KB per call), and enough to
-// tell a different scene that reuses the same addresses from the cached one.
-static uint64_t sceneFingerprint(const void* const* buf, const uint64_t* size) {
-  uint64_t h = 1469598103934665603ull;
-  auto mix = [&h](const unsigned char* p, uint64_t n) {
-    for (uint64_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
-  };
-  for (int b = 0; b < 4; b++) {
-    const unsigned char* p = (const unsigned char*)buf[b];
-    const uint64_t n = size[b];
-    mix((const unsigned char*)&n, sizeof(n));
-    const uint64_t step = n / 4096 + 1;
-    for (uint64_t i = 0; i + 8 <= n; i += step * 8) mix(p + i, 8);
-    mix(p + (n > 256 ? n - 256 : 0), n > 256 ? 256 : n);
-  }
-  return h;
-}
-
 RendererHIP::RendererHIP() : RendererHIP(0) {}
 
 RendererHIP::RendererHIP(int deviceIndex) : context(nullptr) {
   memset(cachedKey, 0, sizeof(cachedKey));
   memset(cachedSize, 0, sizeof(cachedSize));
-  cachedFingerprint = 0;
+  cachedVersion = 0;
   if (lt_hip_create(deviceIndex, &context) != LT_OK) {
     printf("ERROR: RendererHIP: %s\n", lt_hip_last_error(nullptr));
     context = nullptr;
@@ -72,8 +54,27 @@ void RendererHIP::render(void* pRenderProperties) {
                         pAS->getLightContainerBuffer()};
   const uint64_t size[4] = {pAS->getNodeBufferSize(), pAS->getOrderedPrimitiveBufferSize(), pModel->getMaterialBufferSize(),
                             pAS->getLightContainerBufferSize()};
-  const uint64_t fingerprint = sceneFingerprint(key, size);
-  if (memcmp(key, cachedKey, sizeof(key)) != 0 || memcmp(size, cachedSize, sizeof(size)) != 0 || fingerprint != cachedFingerprint) {
+  // extension structs (the reference leaves pNext NULL)
+  const ProgressivePropertiesHIP* progressive = nullptr;
+  const BackendPropertiesHIP* backend = nullptr;
+  for (void* p = props->pNext; p != nullptr;) {
+    const StructureType t = *(StructureType*)p;
+    if (t == STRUCTURE_TYPE_PROGRESSIVE_PROPERTIES_HIP) {
+      progressive = (const ProgressivePropertiesHIP*)p;
+      p = progressive->pNext;
+    } else if (t == STRUCTURE_TYPE_BACKEND_PROPERTIES_HIP) {
+      backend = (const BackendPropertiesHIP*)p;
+      p = backend->pNext;
+    } else {
+      printf("ERROR: unknown sType in the pNext chain of RenderPropertiesHIP\n");
+      break;
+    }
+  }
+  // lt_hip_set_scene hashes the buffers and keeps the resident copy when nothing changed; a caller that versions its scene
+  // skips even that
+  const uint64_t version = backend ? backend->sceneVersion : 0;
+  const bool sameObjects = memcmp(key, cachedKey, sizeof(key)) == 0 && memcmp(size, cachedSize, sizeof(size)) == 0;
+  if (!(sameObjects && version != 0 && version == cachedVersion)) {
     if (lt_hip_set_scene(context, key[0], size[0], key[1], size[1], key[2], size[2], key[3], size[3]) != LT_OK) {
       printf("Kernel Error: %s\n", lt_hip_last_error(context));
       memset(cachedKey, 0, sizeof(cachedKey));
@@ -81,7 +82,7 @@ void RendererHIP::render(void* pRenderProperties) {
     }
     memcpy(cachedKey, key, sizeof(key));
     memcpy(cachedSize, size, sizeof(size));
-    cachedFingerprint = fingerprint;
+    cachedVersion = version;
   }
 
   lt_hip_render_desc desc;
@@ -97,20 +98,14 @@ void RendererHIP::render(void* pRenderProperties) {
     return;
   }
   memcpy(desc.camera, pCamera->getCameraBuffer(), sizeof(desc.camera));
-  for (void* p = props->pNext; p != nullptr;) {
-    StructureType t = *(StructureType*)p;
-    if (t == STRUCTURE_TYPE_PROGRESSIVE_PROPERTIES_HIP) {
-      ProgressivePropertiesHIP* pp = (ProgressivePropertiesHIP*)p;
-      desc.frame_first = pp->frameFirst;
-      desc.frame_count = pp->frameCount;
-      desc.accumulate = pp->accumulate;
-      desc.accumulate_base = pp->accumulateBase;
-      desc.gi_max_depth = pp->giMaxDepth;
-      p = pp->pNext;
-    } else {
-      break;
-    }
+  if (progressive) {
+    desc.frame_first = progressive->frameFirst;
+    desc.frame_count = progressive->frameCount;
+    desc.accumulate = progressive->accumulate;
+    desc.accumulate_base = progressive->accumulateBase;
+    desc.gi_max_depth = progressive->giMaxDepth;
   }
+  if (backend && backend->portableMath) desc.flags |= LT_RENDER_FLAG_PORTABLE_MATH;
   if (lt_hip_render(context, &desc, (float*)props->pOutputBuffer, props->outputBufferSize) != LT_OK) {
     printf("Kernel Error: %s\n", lt_hip_last_error(context));
   }

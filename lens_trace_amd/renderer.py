@@ -41,11 +41,18 @@ class RenderPropertiesHIP:
     giMaxDepth: int = 0
     collectStats: bool = False
     pixelCounters: bool = False                  # diagnostic: per-pixel work counters instead of colour (depth >= 4)
-    deviceLibm: bool = False                     # bit-match ROCm's OpenCL builtins (v_rsq_f32, ocml sinf/cosf, ...)
+    # Floating-point flavour of rsqrt / sqrt / sinf / cosf / clamp.  Default: what ROCm's OpenCL device
+    # library gives the reference kernels on this GPU -- bit-identical to them.  True: the correctly rounded forms the CPU
+    # oracle reproduces (oracle comparisons use this).
+    portableMath: bool = False
+    # 0: every render() hands the scene buffers to lt_hip_set_scene, which hashes them in full and uploads only when the
+    # content changed (the reference uploads on every call).  != 0: the caller versions its scene; the buffers are looked at
+    # again only when the objects or this number change.
+    sceneVersion: int = 0
 
 
 def make_desc(program, W, H, depth, camera28, kernel_mode=KERNEL_MODE_LINEAR, frame_first=0, frame_count=0,
-              accumulate=False, accumulate_base=0, tile=None, gi_max_depth=0, stats=False, pixel_counters=False, device_libm=False):
+              accumulate=False, accumulate_base=0, tile=None, gi_max_depth=0, stats=False, pixel_counters=False, portable_math=False):
     d = C.RenderDesc()
     d.struct_size = ctypes.sizeof(C.RenderDesc)
     d.program, d.kernel_mode = program, kernel_mode
@@ -60,19 +67,8 @@ def make_desc(program, W, H, depth, camera28, kernel_mode=KERNEL_MODE_LINEAR, fr
         d.tile_w, d.tile_h, d.tile_first, d.tile_stride = tile
     d.gi_max_depth = gi_max_depth
     d.flags = ((C.RENDER_FLAG_STATS if stats else 0) | (C.RENDER_FLAG_PIXEL_COUNTERS if pixel_counters else 0) |
-               (C.RENDER_FLAG_DEVICE_LIBM if device_libm else 0))
+               (C.RENDER_FLAG_PORTABLE_MATH if portable_math else 0))
     return d
-
-
-def _fingerprint(arrays):
-    """Cheap content fingerprint of the scene buffers (sizes + a strided sample), so that a different scene that happens to
-    reuse an object id or an address is not mistaken for the cached one."""
-    h = []
-    for a in arrays:
-        b = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
-        step = max(1, b.size // 4096)
-        h.append((b.size, hash(b[::step].tobytes()), hash(b[:256].tobytes()), hash(b[-256:].tobytes())))
-    return tuple(h)
 
 
 class RendererHIP:
@@ -86,6 +82,7 @@ class RendererHIP:
             raise C.LensTraceError(rc, self._L.lt_hip_last_error(None).decode())
         self._scene_key = None
         self._scene_refs = None
+        self._scene_version = 0
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -110,9 +107,9 @@ class RendererHIP:
         for a in arrs:
             args += [a.ctypes.data_as(ctypes.c_void_p), a.nbytes]
         self._check(self._L.lt_hip_set_scene(self._ctx, *args))
-        # the cache key is object identity: keep the objects alive so their ids cannot be recycled by a new scene
+        # keep the objects alive so that their ids cannot be recycled by a new scene
         self._scene_refs = (scene, materials or scene)
-        self._scene_key = (id(scene), id(materials or scene), _fingerprint(arrs))
+        self._scene_key = (id(scene), id(materials or scene))
 
     def invalidate_scene(self):
         """Forget the uploaded scene (call after modifying scene buffers in place)."""
@@ -133,12 +130,14 @@ class RendererHIP:
             raise ValueError("pOutputBuffer must be contiguous float32")
         a = props.pAccelerationStructureExplicit
         m = props.pModel or a
-        key = (id(a), id(m), _fingerprint([a.nodes, a.prims, m.materials, a.lights]))
-        if key != self._scene_key:      # the reference re-uploads on every call; here the upload is cached
+        # the reference re-uploads on every call; lt_hip_set_scene keeps the resident copy when every byte is unchanged
+        key = (id(a), id(m))
+        if not (props.sceneVersion and key == self._scene_key and props.sceneVersion == self._scene_version):
             self.set_scene(a, props.pModel)
+            self._scene_version = props.sceneVersion
         program = self.resolve_program(props.kernelFilePath)
         d = make_desc(program, W, H, D, props.pCamera, props.kernelMode, props.frameFirst, props.frameCount,
-                      props.accumulate, props.accumulateBase, None, props.giMaxDepth, props.collectStats, props.pixelCounters, props.deviceLibm)
+                      props.accumulate, props.accumulateBase, None, props.giMaxDepth, props.collectStats, props.pixelCounters, props.portableMath)
         self._check(self._L.lt_hip_render(self._ctx, ctypes.byref(d), out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
 
     # -- device-resident variants (bench / multi-GPU) -----------------------------------------------------

@@ -30,3 +30,18 @@ def golden_index():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# The HIP path's default floating-point flavour is the reference kernels' own on this GPU (device-library rsqrt / sqrt /
+# sinf / cosf / clamp); the CPU oracle computes the portable, correctly rounded flavour.  Tests that compare with the oracle
+# (or with golden pixels made by it) import these two in place of RenderPropertiesHIP / make_desc.
+def oracle_props(*a, **kw):
+    from lens_trace_amd.renderer import RenderPropertiesHIP
+    kw.setdefault("portableMath", True)
+    return RenderPropertiesHIP(*a, **kw)
+
+
+def oracle_desc(*a, **kw):
+    from lens_trace_amd.renderer import make_desc
+    kw.setdefault("portable_math", True)
+    return make_desc(*a, **kw)

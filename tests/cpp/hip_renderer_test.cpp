@@ -157,6 +157,47 @@ static void RenderBufferTEST_ProgressiveExtension() {
   free(b); free(a);
 }
 
+// beyond the reference's tests: the backend extension struct -- math flavour, and the scene-change contract.  The reference
+// uploads every buffer on every render() (src/opencl/renderer_opencl.cpp:107-120), so an in-place edit of a scene buffer
+// between two calls must show, without any call to invalidateScene().
+static void RenderBufferTEST_BackendExtension() {
+  RendererHIP* renderer = new RendererHIP();
+  uint64_t size = sizeof(float) * 100 * 100 * 3;
+  float* a = (float*)malloc(size); float* b = (float*)malloc(size);
+  Fixture fx;
+  RenderPropertiesHIP rp = fx.props(a, size);
+  renderer->render(&rp);
+  BackendPropertiesHIP bp = {};
+  bp.sType = STRUCTURE_TYPE_BACKEND_PROPERTIES_HIP;
+  bp.portableMath = 1;
+  ProgressivePropertiesHIP pp = {};
+  pp.sType = STRUCTURE_TYPE_PROGRESSIVE_PROPERTIES_HIP;
+  pp.frameFirst = 0; pp.frameCount = 1;
+  bp.pNext = &pp;                      // both extensions in one chain
+  rp.pNext = &bp;
+  rp.pOutputBuffer = b;
+  renderer->render(&rp);
+  for (int x = 0; x < 100 * 100 * 3; x += 32) EXPECT_FLOAT_EQ(a[x], b[x]);   // basic on an unrotated camera: both flavours agree
+  // in-place edit, default contract (sceneVersion 0: content hash): green -> red
+  float* diffuse = (float*)fx.pModel->getMaterialBuffer();
+  diffuse[0] = 1.0f; diffuse[1] = 0.0f;
+  rp.pNext = NULL;
+  renderer->render(&rp);
+  for (int x = 0; x < 100 * 100; x += 8 * 3) { EXPECT_FLOAT_EQ(b[x + 0], 1.0); EXPECT_FLOAT_EQ(b[x + 1], 0.0); }
+  // versioned contract: same version -> the resident scene is used as is; new version -> looked at again
+  bp.pNext = NULL; bp.portableMath = 0; bp.sceneVersion = 7;
+  rp.pNext = &bp;
+  renderer->render(&rp);
+  diffuse[0] = 0.0f; diffuse[2] = 1.0f;   // red -> blue, version unchanged: the caller said nothing changed
+  renderer->render(&rp);
+  EXPECT_FLOAT_EQ(b[0], 1.0); EXPECT_FLOAT_EQ(b[2], 0.0);
+  bp.sceneVersion = 8;
+  renderer->render(&rp);
+  for (int x = 0; x < 100 * 100; x += 8 * 3) { EXPECT_FLOAT_EQ(b[x + 0], 0.0); EXPECT_FLOAT_EQ(b[x + 2], 1.0); }
+  delete renderer;
+  free(b); free(a);
+}
+
 int main(int argc, char** argv) {
   g_dir = argc > 1 ? argv[1] : "/tmp";
   struct { const char* name; void (*fn)(); } tests[] = {
@@ -166,6 +207,7 @@ int main(int argc, char** argv) {
       {"RenderBufferTEST.KernelMode", RenderBufferTEST_KernelMode},
       {"RenderBufferTEST.CorrectColor", RenderBufferTEST_CorrectColor},
       {"RenderBufferTEST.ProgressiveExtension", RenderBufferTEST_ProgressiveExtension},
+      {"RenderBufferTEST.BackendExtension", RenderBufferTEST_BackendExtension},
   };
   int bad = 0;
   for (auto& t : tests) {

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(C.EXPORTS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.lt_hip_abi_version() == 2
+    assert L.lt_hip_abi_version() == 3
 
 
 @pytest.mark.parametrize("path,prog", [
@@ -76,3 +76,25 @@ def test_float_thresholds_equal_the_double_epsilon_compares():
         for eps, bits in ((0.0001, 0x38d1b718), (0.0000001, 0x33d6bf95)):
             thr = np.array([bits], dtype=np.uint32).view(np.float32)[0]
             assert (float(x) < eps) == bool(x < thr)
+
+
+def test_bench_roofline_is_a_fraction_of_a_stated_peak():
+    """bench.py's roofline object for the headline workload comes from the committed counter profile of the same command
+    (profiles/r*/issue_profile.json, hbm_traffic.json): frac <= 1 against the stated pipe peak, the HBM figures beside it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    key = "synthetic height-field wall, 1002530 triangles, 3840x2160, accumulator"
+    prof = bench._latest_profile("issue_profile.json", key)
+    if prof is None:
+        import pytest
+        pytest.skip("no issue_profile.json for the headline workload committed yet")
+    launch_ms = prof["launch_ms_under_profiler"]
+    r = bench.roofline(key, "lt_render_kernel<accumulator>", launch_ms, 1.0, 16, 1.38e12, True)
+    assert r["bound"] in ("valu-issue", "scalar-issue") and 0.0 < r["frac"] <= 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.0 < r["hbm_measured_frac"] <= 1.0 and r["traffic"] > 0 and r["on_chip_reuse_factor"] > 1.0
+    # no profile for another workload: nothing claimed
+    r2 = bench.roofline("some other workload", "k", 1.0, 1.0, 16, 1e9, True)
+    assert r2["frac"] is None and r2["traffic"] is None

@@ -8,8 +8,9 @@ import pytest
 
 from lens_trace_amd import _capi as C
 from lens_trace_amd import scene as sc
-from lens_trace_amd.renderer import KERNEL_MODE_TILE, RendererHIP, RenderPropertiesHIP
+from lens_trace_amd.renderer import KERNEL_MODE_TILE, RendererHIP
 from oracle import pyoracle as po
+from tests.conftest import oracle_props as RenderPropertiesHIP   # the flavour the CPU oracle reproduces
 
 pytestmark = pytest.mark.gpu
 

@@ -5,7 +5,10 @@ oracle itself is consulted on sampled rows:
   * tile-sharded render (8 ranks' worth, rendered one after another on this GPU) + untile == whole-frame render;
   * the 16-sample device-side running mean == folding 16 single-frame renders with accumulator.frag's formula;
   * tileKernel output clamped == linearKernel output (SURVEY Q14);
-  * ray bookkeeping: rays == pixels + shadow rays, every pixel rendered once."""
+  * ray bookkeeping: rays == pixels + shadow rays, every pixel rendered once;
+  * the WHOLE 4K frame, in the default flavour (what bench.py times), == the reference's own accumulator.cl compiled for
+    gfx950 (oracle/ref_gpu.py) run on the same 1 M-triangle buffers, bit for bit, with either shadow-ray walk forced, camera
+    unrotated and rotated."""
 import numpy as np
 import pytest
 
@@ -13,8 +16,10 @@ from lens_trace_amd import _capi as C
 from lens_trace_amd import scene as sc
 from lens_trace_amd import synth
 from lens_trace_amd.dist import TilePlan
-from lens_trace_amd.renderer import KERNEL_MODE_TILE, RendererHIP, RenderPropertiesHIP, make_desc
+from lens_trace_amd.renderer import KERNEL_MODE_TILE, RendererHIP
 from oracle import pyoracle as po
+from tests.conftest import oracle_desc as make_desc
+from tests.conftest import oracle_props as RenderPropertiesHIP   # the flavour the CPU oracle reproduces
 
 pytestmark = pytest.mark.gpu
 W, H = 3840, 2160
@@ -142,3 +147,25 @@ def test_tile_mode_clamped_equals_linear_mode(renderer, wall):
     til = render(renderer, wall, 5, kernelMode=KERNEL_MODE_TILE)
     assert np.array_equal(np.clip(til, 0.0, 1.0), lin)
     assert til.min() < 0.0      # back-facing n.l survives in tile mode
+
+
+# ---- the timed kernel against the reference itself, at full size --------------------------------------------------------
+@pytest.mark.parametrize("yaw", [0.0, 0.03])
+def test_whole_4k_frame_matches_reference_accumulator_kernel(renderer, wall, monkeypatch, yaw):
+    """examples/accumulator/resources/kernels/accumulator.cl:113-217 (one work-item per pixel, private 64-entry stack) on the
+    1 002 530-triangle buffers at 3840x2160 against the HIP path's default flavour: packet walks over pair records, octant
+    switches, the 20-row LDS stack, slow-path squares first, both shadow-ray walks.  Bit for bit."""
+    from lens_trace_amd.renderer import RenderPropertiesHIP as DefaultFlavourProps
+    from oracle import ref_gpu
+    if not ref_gpu.available("accumulator"):
+        pytest.skip("oracle/_ref/accumulator.strict.co not built (needs /root/reference at build time)")
+    cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, 2)
+    ref = ref_gpu.render(wall, cam, W, H, "accumulator", "strict")
+    assert ref.shape == (H, W, 3) and ref.sum() > 0
+    for packets in ("1", "0"):
+        monkeypatch.setenv("LT_SHADOW_PACKETS", packets)
+        got = np.empty((H, W, 3), dtype=np.float32)
+        renderer.render(DefaultFlavourProps(ACC, (W, H, 3), got, wall, pCamera=cam))
+        assert renderer.stats()["shadow_packets"] == int(packets)
+        ndiff = int((got != ref).sum())
+        assert ndiff == 0, "yaw %g, LT_SHADOW_PACKETS=%s: %d of %d floats differ from the reference kernel" % (yaw, packets, ndiff, ref.size)

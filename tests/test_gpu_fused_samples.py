@@ -12,9 +12,11 @@ from lens_trace_amd import _capi as C
 from lens_trace_amd import scene as sc
 from lens_trace_amd import synth
 from lens_trace_amd.dist import TilePlan, untile_numpy
-from lens_trace_amd.renderer import RendererHIP, RenderPropertiesHIP, make_desc
+from lens_trace_amd.renderer import RendererHIP
 from oracle import pyoracle as po
 from tests.conftest import GOLDEN
+from tests.conftest import oracle_desc as make_desc
+from tests.conftest import oracle_props as RenderPropertiesHIP   # the flavour the CPU oracle reproduces
 
 pytestmark = pytest.mark.gpu
 ACC = "examples/accumulator/resources/kernels/accumulator.cl"
@@ -263,3 +265,27 @@ def test_random_scheduling_configurations(renderer, cornell, monkeypatch, seed):
         got, got_tiled = render_all(env)
         assert np.array_equal(got, want), (prog_name, W, H, count, first, base, depth, env)
         assert np.array_equal(got_tiled, want), (prog_name, W, H, count, first, base, depth, tile, env)
+
+
+@pytest.mark.parametrize("path", [ACC, GI])
+def test_fused_launch_with_depth_4_leaves_the_fourth_channel_alone(renderer, cornell, monkeypatch, path):
+    """imageDimensions[2] > 3: only channels 0..2 of a pixel are written (accumulator.cl:316-318 writes three floats at
+    (y*W+x)*depth); the fold of a fused launch must neither average scratch memory into the others nor differ from one launch
+    per sample."""
+    W, H, count = 72, 40, 5
+    monkeypatch.setenv("LT_GI_MEGAKERNEL", "1")
+
+    def run():
+        out = np.full((H, W, 4), 7.5, dtype=np.float32)
+        renderer.render(RenderPropertiesHIP(path, (W, H, 4), out, cornell, pCamera=CAM, frameFirst=1, frameCount=count, accumulate=True))
+        return out, renderer.stats()
+    fused, st = run()
+    assert st["kernel_launches"] == 1
+    monkeypatch.setenv("LT_FUSED_FRAMES", "0")
+    single, st = run()
+    assert st["kernel_launches"] == count
+    assert np.array_equal(fused, single)
+    # (lt_hip_render stages through a zeroed device buffer: what was never written reads back 0, never scratch contents)
+    assert np.all(fused[..., 3] == 0.0) and np.all(single[..., 3] == 0.0)
+    three, _ = frames(renderer, cornell, path, W, H, 1, count)
+    assert np.array_equal(fused[..., :3], three)

@@ -11,10 +11,11 @@ import pytest
 
 from lens_trace_amd import _capi as C
 from lens_trace_amd import scene as sc
-from lens_trace_amd.renderer import (KERNEL_MODE_LINEAR, KERNEL_MODE_TILE, RendererHIP, RenderPropertiesHIP,
-                                     make_desc)
+from lens_trace_amd.renderer import KERNEL_MODE_LINEAR, KERNEL_MODE_TILE, RendererHIP
 from oracle import pyoracle as po
 from tests.conftest import GOLDEN, golden_index
+from tests.conftest import oracle_desc as make_desc
+from tests.conftest import oracle_props as RenderPropertiesHIP   # the flavour the CPU oracle reproduces
 
 pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-4
@@ -240,3 +241,30 @@ def test_gi_tile_sharding(renderer, monkeypatch, force):
     renderer.untile(gathered.data_ptr(), per_rank, ranks, W, H, 3, tile[0], tile[1], image.data_ptr(), stream)
     torch.cuda.synchronize()
     assert np.array_equal(image.cpu().numpy(), whole)
+
+
+def test_in_place_scene_edits_show_without_any_invalidate_call(renderer):
+    """The reference uploads every scene buffer on every render() (src/opencl/renderer_opencl.cpp:107-120).  Here the resident
+    copy is kept only while lt_hip_set_scene's hash of EVERY byte is unchanged: an edit of any single vertex / material shows."""
+    import copy
+    s = copy.deepcopy(load("cornell_box_O0"))
+    before = renderer.stats()
+    a = render(renderer, s, KERNEL_PATHS["basic"], 64, 64, CAM)
+    b = render(renderer, s, KERNEL_PATHS["basic"], 64, 64, CAM)
+    st = renderer.stats()
+    assert np.array_equal(a, b)
+    # (the copy has the content of a scene an earlier test may have left resident: at most one upload, at least one reuse)
+    assert st["scene_uploads"] <= before["scene_uploads"] + 1 and st["scene_reused"] >= before["scene_reused"] + 1
+    # one float of one material, somewhere in the middle of the buffer (a strided sample would miss it)
+    mats = s.materials.view(np.float32).reshape(-1, 8)
+    mats[len(mats) // 2, 1] += 0.25
+    c = render(renderer, s, KERNEL_PATHS["basic"], 64, 64, CAM)
+    assert renderer.stats()["scene_uploads"] == st["scene_uploads"] + 1
+    assert not np.array_equal(a, c)
+    assert np.array_equal(c, po.render(s, CAM, 64, 64, po.BASIC))
+    # a versioned scene is not looked at again until its version changes
+    d = render(renderer, s, KERNEL_PATHS["basic"], 64, 64, CAM, sceneVersion=3)
+    mats[len(mats) // 2, 1] -= 0.25
+    e = render(renderer, s, KERNEL_PATHS["basic"], 64, 64, CAM, sceneVersion=3)
+    f = render(renderer, s, KERNEL_PATHS["basic"], 64, 64, CAM, sceneVersion=4)
+    assert np.array_equal(d, c) and np.array_equal(e, c) and np.array_equal(f, a)

@@ -1,19 +1,26 @@
 """GPU cross-check (-m gpu) against the REFERENCE's own OpenCL kernels, compiled for gfx950 from the reference
 sources by oracle/build_ref.sh with the image's real OpenCL device libraries and launched through the HIP module
 API (oracle/ref_gpu.py).  This is what pins the programs the reference's own tests do not cover (accumulator,
-basic_lighting, global_illumination, lens).
+basic_lighting, global_illumination, lens), and the traversal machinery the benchmark times (packet walks over
+child-pair records, any-hit shadow packets, per-XCD persistent queues, fused multi-sample launches) against
+examples/accumulator/resources/kernels/accumulator.cl:113-217 itself rather than against the CPU restatement.
 
-Against the "strict" build (-ffp-contract=off, correctly rounded divide/sqrt) the HIP path is run with
-LT_RENDER_FLAG_DEVICE_LIBM, which swaps in the device library's rsqrt / sqrt / sinf / cosf / clamp (the only leaf
-functions where ROCm's OpenCL library is not plain IEEE): expected BIT-IDENTICAL, asserted as RMS <= 1e-4
-(north_star) plus a bound on the number of differing floats.  The portable flavour (the one the CPU oracle
-reproduces) differs from it by <= 1-2 ulp in those leaf functions; that is reported alongside."""
+Against the "strict" build (-ffp-contract=off, correctly rounded divide/sqrt) the HIP path in its DEFAULT flavour --
+what RendererHIP::render, the Python mirror, the CLI and bench.py run -- must be BIT-IDENTICAL (asserted: RMS <= 1e-4,
+north_star, and zero differing floats).  The portable flavour (LT_RENDER_FLAG_PORTABLE_MATH, the one the CPU oracle
+reproduces) differs from the reference kernels by <= 1-2 ulp in four leaf functions; that gap is asserted too:
+<= 1e-4 RMS for the programs without random() amplification, a bound on the flipped pixels for the others.
+
+Against the reference's as-shipped build options (NULL: contraction allowed, approximate divide/sqrt;
+src/opencl/renderer_opencl.cpp:50) the difference is reported for all six programs and asserted only for the programs
+whose expressions have no contractable a*b+c on a decision path."""
 import os
 
 import numpy as np
 import pytest
 
 from lens_trace_amd import scene as sc
+from lens_trace_amd import synth
 from lens_trace_amd.renderer import RendererHIP, RenderPropertiesHIP
 from oracle import ref_gpu
 from tests.conftest import GOLDEN
@@ -50,6 +57,17 @@ CASES = [  # scene, kernel, mode, W, H, frame
 CASES = [c if len(c) == 7 else c + (0.0,) for c in CASES]
 
 
+def portable_pixel_bound(kernel, pixels):
+    """Pixels the portable flavour may have off by > 1e-4 against the reference kernels.  The programs that feed
+    normalize() / sinf / cosf results into random()-driven ray decisions flip a decision in ~0.03 % of pixel-samples
+    (round 1 measured 2-17 pixels of 64^2..256^2); the 25-sample variants have 25 chances per pixel."""
+    if kernel in ("basic", "custom_opencl", "accumulator"):
+        return 0
+    if kernel in ("basic_lighting", "global_illumination25"):
+        return 2 + pixels // 100
+    return 2 + pixels // 1000
+
+
 @pytest.fixture(scope="module")
 def renderer():
     if not ref_gpu.available():
@@ -59,6 +77,20 @@ def renderer():
     r.close()
 
 
+def hip(renderer, s, kernel, W, H, cam, mode=0, **kw):
+    out = np.empty((H, W, 3), dtype=np.float32)
+    renderer.render(RenderPropertiesHIP(PATHS[kernel], (W, H, 3), out, s, pCamera=cam, kernelMode=mode, **kw))
+    return out
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def pixels_off(a, b):
+    return int((np.abs(a.astype(np.float64) - b).max(axis=2) > 1e-4).sum())
+
+
 @pytest.mark.parametrize("scene,kernel,mode,W,H,frame,yaw", CASES)
 def test_hip_matches_reference_kernel_strict(renderer, monkeypatch, scene, kernel, mode, W, H, frame, yaw):
     if "global_illumination" in kernel:
@@ -66,36 +98,111 @@ def test_hip_matches_reference_kernel_strict(renderer, monkeypatch, scene, kerne
     s = sc.load_ltsb(os.path.join(GOLDEN, scene + ".ltsb")).validate()
     cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, frame)
     ref = ref_gpu.render(s, cam, W, H, kernel, "strict", mode)
-    got = np.empty((H, W, 3), dtype=np.float32)
-    renderer.render(RenderPropertiesHIP(PATHS[kernel], (W, H, 3), got, s, pCamera=cam, kernelMode=mode, deviceLibm=True))
-    port = np.empty((H, W, 3), dtype=np.float32)
-    renderer.render(RenderPropertiesHIP(PATHS[kernel], (W, H, 3), port, s, pCamera=cam, kernelMode=mode))
-    diff = got.astype(np.float64) - ref
-    rms = float(np.sqrt(np.mean(diff ** 2)))
+    got = hip(renderer, s, kernel, W, H, cam, mode)                       # the default flavour: what every caller gets
+    port = hip(renderer, s, kernel, W, H, cam, mode, portableMath=True)   # the CPU oracle's flavour
     nbits = int((got != ref).sum())
-    pdiff = port.astype(np.float64) - ref
-    print("REF-strict %s/%s m%d %dx%d f%d: device-libm rms=%.3g floats_differing=%d/%d | portable rms=%.3g pixels_off_by_1e-4=%d" % (
-        scene, kernel, mode, W, H, frame, rms, nbits, ref.size, float(np.sqrt(np.mean(pdiff ** 2))),
-        int((np.abs(pdiff).max(axis=2) > 1e-4).sum())))
+    poff = pixels_off(port, ref)
+    print("REF-strict %s/%s m%d %dx%d f%d: default rms=%.3g floats_differing=%d/%d | portable rms=%.3g pixels_off_by_1e-4=%d (bound %d)" % (
+        scene, kernel, mode, W, H, frame, rms(got, ref), nbits, ref.size, rms(port, ref), poff, portable_pixel_bound(kernel, W * H)))
     assert ref.sum() > 0
-    assert rms <= RMS_TOL
+    assert rms(got, ref) <= RMS_TOL
     assert nbits == 0
+    # the portable flavour: a tracked number, not a print
+    if portable_pixel_bound(kernel, W * H) == 0:
+        assert rms(port, ref) <= RMS_TOL
+    assert poff <= portable_pixel_bound(kernel, W * H)
 
 
-@pytest.mark.parametrize("scene,kernel,mode,W,H,frame,yaw", [c for c in CASES if c[1] in ("basic", "accumulator")][:5])
-def test_report_against_default_build_options(renderer, scene, kernel, mode, W, H, frame, yaw):
-    """Informational: the reference passes NULL build options (renderer_opencl.cpp:50), which lets the OpenCL
-    compiler contract a*b+c and use approximate divide/sqrt.  basic must still agree to the tolerance; for the
-    stochastic programs the difference is reported, not asserted (contraction inside user expressions moves
-    hit points by ulps; rays near an edge can flip)."""
+DEFAULT_CASES = [  # one per program + the lens path + a tile-mode case
+    ("green_wall_O0", "basic", 0, 100, 100, 0),
+    ("cornell_box_O0", "basic", 0, 128, 128, 0),
+    ("cornell_box_lens_O0", "basic", 0, 128, 128, 0),
+    ("cornell_box_O0", "custom_opencl", 0, 128, 128, 0),
+    ("cornell_box_O0", "accumulator", 0, 128, 128, 0),
+    ("cornell_box_O0", "accumulator", 1, 128, 128, 7),
+    ("cornell_box_O0", "basic_lighting", 0, 64, 64, 1),
+    ("cornell_box_O0", "global_illumination", 0, 128, 128, 0),
+    ("cornell_box_O0", "global_illumination", 0, 256, 256, 3),
+    ("cornell_box_O0", "global_illumination25", 0, 64, 64, 2),
+]
+
+
+@pytest.mark.parametrize("scene,kernel,mode,W,H,frame", DEFAULT_CASES)
+def test_report_against_default_build_options(renderer, scene, kernel, mode, W, H, frame):
+    """The reference passes NULL build options (renderer_opencl.cpp:50), which lets the OpenCL compiler contract a*b+c
+    and use approximate divide/sqrt: which expressions it contracts is the compiler's choice of the day, so the contract
+    fixed here is the strict build.  Reported for all six programs; asserted at 1e-4 RMS for `basic`
+    (its colour is a material constant: only a flipped hit shows), and bounded in flipped pixels elsewhere (4 x the strict
+    build's portable-flavour bound) so that a regression of the default flavour shows.  Round 2 on the MI355X: basic 0 px,
+    lens 2 px, custom_opencl 1 px, accumulator 1 px, basic_lighting 1 px of 64^2, GI 20 px of 128^2 / 51 px of 256^2,
+    GI-25 41 px of 64^2."""
     s = sc.load_ltsb(os.path.join(GOLDEN, scene + ".ltsb")).validate()
     cam = sc.camera_bytes(0.0, 2.5, -50.0, 0.0, 0.0, 0.0, frame)
     ref = ref_gpu.render(s, cam, W, H, kernel, "default", mode)
-    got = np.empty((H, W, 3), dtype=np.float32)
-    renderer.render(RenderPropertiesHIP(PATHS[kernel], (W, H, 3), got, s, pCamera=cam, kernelMode=mode))
-    diff = got.astype(np.float64) - ref
-    rms = float(np.sqrt(np.mean(diff ** 2)))
-    print("REF-default %s/%s m%d %dx%d f%d: rms=%.3g pixels_off_by_1e-4=%d" % (
-        scene, kernel, mode, W, H, frame, rms, int((np.abs(diff).max(axis=2) > 1e-4).sum())))
+    got = hip(renderer, s, kernel, W, H, cam, mode)
+    poff = pixels_off(got, ref)
+    print("REF-default %s/%s m%d %dx%d f%d: rms=%.3g pixels_off_by_1e-4=%d floats_differing=%d/%d" % (
+        scene, kernel, mode, W, H, frame, rms(got, ref), poff, int((got != ref).sum()), ref.size))
     if kernel == "basic" and scene != "cornell_box_lens_O0":   # lens: refract() has contractable a*b+c chains
-        assert rms <= RMS_TOL
+        assert rms(got, ref) <= RMS_TOL                        # (custom_opencl's colour IS (u, v, 1-u-v): contraction inside
+                                                               #  intersectTriangle shows in every float, and flips an edge pixel)
+    else:
+        assert poff <= 4 * (2 + W * H // (100 if kernel in ("basic_lighting", "global_illumination25") else 1000))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The machinery the benchmark times, against the reference's accumulator.cl on big synthetic scenes.
+_synth = {}
+
+
+def synth_scene(name):
+    if name not in _synth:
+        _synth[name] = {"wall": lambda: synth.heightfield_wall(128), "soup": lambda: synth.triangle_soup(40000),
+                        "blob": lambda: synth.blob_in_box(4)}[name]().validate()
+    return _synth[name]
+
+
+@pytest.mark.parametrize("packets", ["0", "1"])
+@pytest.mark.parametrize("name,frame,yaw", [("wall", 1, 0.0), ("wall", 6, 0.03), ("soup", 2, 0.0), ("soup", 3, -0.02), ("blob", 1, 0.0),
+                                            ("blob", 4, 0.05)])
+def test_big_scenes_both_shadow_walks_match_reference_accumulator(renderer, monkeypatch, name, frame, yaw, packets):
+    """Packet walks, pair records, octant switches, any-hit shadow packets (LT_SHADOW_PACKETS=1) and the per-lane walk (=0),
+    image-centre row / column squares included (256 is even), against accumulator.cl's own traversal."""
+    monkeypatch.setenv("LT_SHADOW_PACKETS", packets)
+    s = synth_scene(name)
+    W = H = 256
+    cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, frame)
+    ref = ref_gpu.render(s, cam, W, H, "accumulator", "strict")
+    got = hip(renderer, s, "accumulator", W, H, cam)
+    assert ref.sum() > 0
+    assert int((got != ref).sum()) == 0, "%s f%d yaw %g packets %s: %d floats differ, rms %.3g" % (
+        name, frame, yaw, packets, int((got != ref).sum()), rms(got, ref))
+
+
+@pytest.mark.parametrize("packets", ["0", "1"])
+@pytest.mark.parametrize("name", ["wall", "soup"])
+def test_fused_running_mean_matches_reference_frames_folded(renderer, monkeypatch, name, packets):
+    """The fused multi-sample launch + lt_running_mean_kernel against reference frames folded with accumulator.frag's
+    expression (examples/accumulator/resources/shaders/accumulator.frag:10-20) in float32."""
+    monkeypatch.setenv("LT_SHADOW_PACKETS", packets)
+    s = synth_scene(name)
+    W, H, first, count = 200, 136, 3, 5
+    acc = None
+    for k in range(count):
+        c = ref_gpu.render(s, sc.camera_bytes(0.0, 2.5, -50.0, 0.0, 0.0, 0.0, first + k), W, H, "accumulator", "strict")
+        acc = c if k == 0 else ((c + acc * np.float32(k)) / np.float32(k + 1)).astype(np.float32)
+    got = hip(renderer, s, "accumulator", W, H, sc.camera_bytes(0.0, 2.5, -50.0), frameFirst=first, frameCount=count, accumulate=True)
+    assert renderer.stats()["kernel_launches"] <= 3      # one fused render launch (+ its twin when the walk is being timed) + the fold
+    assert int((got != acc).sum()) == 0, "rms %.3g" % rms(got, acc)
+
+
+def test_global_illumination_pipeline_on_a_big_scene_matches_reference(renderer, monkeypatch):
+    """The wavefront GI pipeline (path queues, compaction, fused frames) on a scene large enough to select it."""
+    s = synth_scene("wall")
+    W = H = 128
+    cam = sc.camera_bytes(0.0, 2.5, -50.0, 0.01, 0.0, 0.0, 2)
+    ref = ref_gpu.render(s, cam, W, H, "global_illumination", "strict")
+    for mega in ("0", "1"):
+        monkeypatch.setenv("LT_GI_MEGAKERNEL", mega)
+        got = hip(renderer, s, "global_illumination", W, H, cam)
+        assert int((got != ref).sum()) == 0, "LT_GI_MEGAKERNEL=%s: rms %.3g" % (mega, rms(got, ref))

@@ -8,9 +8,10 @@ import pytest
 
 from lens_trace_amd import scene as sc
 from lens_trace_amd import synth
-from lens_trace_amd.renderer import KERNEL_MODE_TILE, RendererHIP, RenderPropertiesHIP
+from lens_trace_amd.renderer import KERNEL_MODE_TILE, RendererHIP
 from oracle import pyoracle as po
 from tests.conftest import GOLDEN
+from tests.conftest import oracle_props as RenderPropertiesHIP   # the flavour the CPU oracle reproduces
 
 pytestmark = pytest.mark.gpu
 PATHS = {"accumulator": "examples/accumulator/resources/kernels/accumulator.cl",

@@ -8,9 +8,10 @@ import pytest
 
 from lens_trace_amd import _capi as C
 from lens_trace_amd import scene as sc
-from lens_trace_amd.renderer import RendererHIP, RenderPropertiesHIP
+from lens_trace_amd.renderer import RendererHIP
 from oracle import pyoracle as po
 from tests.conftest import GOLDEN
+from tests.conftest import oracle_props as RenderPropertiesHIP   # the flavour the CPU oracle reproduces
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "user_kernels")

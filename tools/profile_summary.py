@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 passes of tools/collect_profiles.sh into the two summaries bench.py reads:
+
+  hbm_traffic.json   : HBM bytes per launch of the dominant kernel = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes; the factor 2 is
+                       MI355X_MICROARCH.md's gfx950 correction for wide coalesced reads)
+  issue_profile.json : what the kernel's wave-cycles are spent on and how busy each issue pipe is, against the peaks of
+                       MI355X_MICROARCH.md (wave64 VALU: 2 cycles per instruction per SIMD-32, so 0.5 wave-instructions per
+                       SIMD-cycle; one scalar instruction per CU-cycle)
+
+usage: profile_summary.py <gpurun_out/prof_rN> "<command the passes profiled>" """
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+out_dir = sys.argv[1]
+command = sys.argv[2] if len(sys.argv) > 2 else ""
+
+
+def counters(name):
+    """{kernel: {counter: mean per dispatch}} of one pass, and {kernel: dispatches}"""
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(out_dir, name, "*", "*_counter_collection.csv")):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+def dominant(per_kernel, counter):
+    """the non-counting render kernel (or GI stage set) with the largest total of `counter`"""
+    best = None
+    for k, cs in per_kernel.items():
+        m = re.search(r"Config<(\w+), (\w+), (\w+)>", k)
+        if "lt_" not in k or (m and m.group(2) == "true"):   # (Config<DEEP, STATS, DEVLIBM>: skip the counting instantiations)
+            continue
+        if counter in cs and (best is None or cs[counter] > per_kernel[best][counter]):
+            best = k
+    return best
+
+
+passes = {n: counters(n) for n in ("fetch", "write", "issue", "pipes", "insts", "sqc", "cache")}
+bench = {}
+try:
+    bench = json.loads(open(os.path.join(out_dir, "stats.log")).read().strip().splitlines()[-1])
+except Exception:
+    pass
+
+# kernel duration from the --stats pass
+dur_ms = {}
+for f in glob.glob(os.path.join(out_dir, "stats", "*", "*_kernel_stats.csv")):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            dur_ms[row["Name"]] = (float(row["AverageNs"]) / 1e6, int(row["Calls"]))
+
+kern = dominant(passes["issue"], "SQ_WAVE_CYCLES") or dominant(passes["fetch"], "FETCH_SIZE")
+if kern is None:
+    sys.exit("no lt_ kernel found in the counter passes")
+ms, calls = dur_ms.get(kern, (None, 0))
+# bench.py's workload key: "<scene name>, <n> triangles, <W>x<H>, <program>"
+key = (bench.get("config") or {}).get("workload_key", "")
+
+if kern in passes["fetch"] and kern in passes["write"]:
+    fetch_kb, write_kb = passes["fetch"][kern]["FETCH_SIZE"], passes["write"][kern]["WRITE_SIZE"]
+    hbm = {"command": command, "kernel": kern, "workload": key, "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+           "correction": "gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE as reported",
+           "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024), "launch_ms_under_profiler": ms}
+    json.dump(hbm, open(os.path.join(out_dir, "hbm_traffic.json"), "w"), indent=1)
+    print("hbm_traffic.json:", hbm["hbm_bytes_per_launch"] / 1e9, "GB per launch")
+
+c = {}
+for n in ("issue", "pipes", "insts", "sqc", "cache"):
+    c.update(passes[n].get(kern, {}))
+if "SQ_WAVE_CYCLES" in c:
+    CUS, SIMDS = 256, 1024
+    # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants); GRBM_GUI_ACTIVE is
+    # summed over the 8 XCDs
+    cycles = c.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    if not cycles and ms:
+        cycles = ms * 1e-3 * 2.4e9
+    wave_quads = c["SQ_WAVE_CYCLES"]
+    prof = {"command": command, "kernel": kern, "workload": key, "launch_ms_under_profiler": ms, "shader_cycles_per_launch": cycles,
+            "effective_clock_ghz": (cycles / (ms * 1e-3) / 1e9) if ms else None, "raw": c}
+    frac = lambda x: (c[x] / wave_quads) if x in c else None
+    prof["wave_cycle_split"] = {"waiting_on_memory_or_barrier (SQ_WAIT_ANY)": frac("SQ_WAIT_ANY"),
+                                "issue_stalled (SQ_WAIT_INST_ANY)": frac("SQ_WAIT_INST_ANY"),
+                                "executing (SQ_ACTIVE_INST_ANY)": frac("SQ_ACTIVE_INST_ANY")}
+    if cycles:
+        pipes = {}
+        if "SQ_INSTS_VALU" in c:
+            pipes["valu"] = {"wave_instructions_per_simd_cycle": c["SQ_INSTS_VALU"] / SIMDS / cycles, "peak": 0.5,
+                             "frac": c["SQ_INSTS_VALU"] / SIMDS / cycles / 0.5}
+        if "SQ_INSTS_SALU" in c:
+            n = c["SQ_INSTS_SALU"] + c.get("SQ_INSTS_SMEM", 0.0)
+            pipes["scalar"] = {"instructions_per_cu_cycle (SALU + SMEM)": n / CUS / cycles, "peak": 1.0, "frac": n / CUS / cycles,
+                               "salu_only_frac": c["SQ_INSTS_SALU"] / CUS / cycles}
+        if "SQ_INSTS_VMEM_RD" in c:
+            pipes["vmem"] = {"instructions_per_cu_cycle": (c["SQ_INSTS_VMEM_RD"] + c.get("SQ_INSTS_VMEM_WR", 0)) / CUS / cycles}
+        if "SQ_INSTS_LDS" in c:
+            pipes["lds"] = {"instructions_per_cu_cycle": c["SQ_INSTS_LDS"] / CUS / cycles}
+        if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+            pipes["valu"]["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        if "TA_BUSY_avr" in c:
+            pipes["texture_addresser_busy"] = c["TA_BUSY_avr"] / cycles
+        prof["pipes"] = pipes
+    if "SQC_ICACHE_REQ" in c:
+        prof["instruction_cache"] = {"requests": c["SQC_ICACHE_REQ"], "hit_rate": c["SQC_ICACHE_HITS"] / max(c["SQC_ICACHE_REQ"], 1.0),
+                                     "misses": c["SQC_ICACHE_MISSES"], "misses_per_1000_instructions":
+                                         1000.0 * c["SQC_ICACHE_MISSES"] / max(c.get("SQ_INSTS_VALU", 0) + c.get("SQ_INSTS_SALU", 0), 1.0)}
+    if "SQC_DCACHE_REQ" in c:
+        prof["scalar_cache"] = {"requests": c["SQC_DCACHE_REQ"], "hit_rate": c["SQC_DCACHE_HITS"] / max(c["SQC_DCACHE_REQ"], 1.0),
+                                "misses": c["SQC_DCACHE_MISSES"]}
+    if "TCC_HIT_sum" in c:
+        prof["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0)
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+        prof["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / max(c["TCP_TOTAL_CACHE_ACCESSES_sum"], 1.0)
+    # the binding class: the busiest issue pipe, unless the waves spend most of their cycles parked on memory
+    cand = {k: v["frac"] for k, v in prof.get("pipes", {}).items() if isinstance(v, dict) and "frac" in v}
+    if cand:
+        top = max(cand, key=cand.get)
+        prof["bound"] = {"class": {"valu": "valu-issue", "scalar": "scalar-issue"}[top], "frac": cand[top], "all": cand}
+    json.dump(prof, open(os.path.join(out_dir, "issue_profile.json"), "w"), indent=1)
+    print(json.dumps({k: v for k, v in prof.items() if k != "raw"}, indent=1))
