@@ -201,6 +201,40 @@ __device__ __forceinline__ bool intersect_triangle(const float4* __restrict__ tr
   return intersect_triangle_data<PROGRAM>(t[0], t[1], t[2], ray, pl);
 }
 
+// The same test for the packet walks, where the triangle sits in SGPRs and the whole wave runs it anyway: no per-lane early
+// outs (each one costs an exec-mask save / restore and a copy of the payload through every exit), one wave-uniform exit after
+// the `u` test, selects at the end.  `active` = this lane visits the leaf.  Same predicates in the same negated forms as the
+// reference's `return false` tests, so a NaN falls through exactly where it does there; lanes that are not active compute on
+// whatever their registers hold and are masked out of every decision (no float exception traps on this path).
+template <int PROGRAM>
+__device__ __forceinline__ bool intersect_triangle_packet(const float4 t0, const float4 t1, const float4 t2, const Ray& ray, Hit& pl,
+                                                          bool active, int prim) {
+  const V4 A = mk4(t0.x, t0.y, t0.z, 1.0f);
+  const V4 v0v1 = mk4(t0.w, t1.x, t1.y, 0.0f);
+  const V4 v0v2 = mk4(t1.z, t1.w, t2.x, 0.0f);
+  const V4 pvec = cross4(ray.d, v0v2);
+  const float det = dot4(v0v1, pvec);
+  const float eps = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
+                    : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
+  bool ok = active && !(__builtin_fabsf(det) < eps);
+  const float invDet = 1.0f / det;
+  const V4 tvec = sub4(ray.o, A);
+  const float u = dot4(tvec, pvec) * invDet;
+  ok = ok && !(u < 0.0f || u > 1.0f);
+  if (__builtin_amdgcn_ballot_w64(ok) == 0ull) return false;
+  const V4 qvec = cross4(tvec, v0v1);
+  const float v = dot4(ray.d, qvec) * invDet;
+  ok = ok && !(v < 0.0f || u + v > 1.0f);
+  const float tt = dot4(v0v2, qvec) * invDet;
+  ok = ok && (tt < pl.t);
+  pl.t = ok ? tt : pl.t;
+  pl.u = ok ? u : pl.u;
+  pl.v = ok ? v : pl.v;
+  pl.prim = ok ? prim : pl.prim;
+  pl.hitType = ok ? 1 : pl.hitType;
+  return ok;
+}
+
 // The per-lane traversal stack: entries [0,kLdsStack) live in LDS (column `lane`, row stride kBlock, so
 // every wave access is one conflict-free row), deeper entries (only for BVHs deeper than kLdsStack, chosen
 // by the host from the scene's measured height) in a per-lane scratch array.
@@ -491,14 +525,18 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
   const int lane = (int)__lane_id();
   constexpr uint32_t negBitsU = (uint32_t)NEG;   // the direction signs the whole wave shares, a compile-time constant here
   auto leaf_test = [&](uint32_t off, u64 m) {
+    const ConstF4 t = tris + 3 * (size_t)off;
+    const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
+#ifndef LT_BRANCHY_PACKET_LEAF
+    intersect_triangle_packet<PROGRAM>(t0, t1, t2, ray, pl, ((m >> lane) & 1ull) != 0ull, (int)off);
+#else
     if ((m >> lane) & 1ull) {
-      const ConstF4 t = tris + 3 * (size_t)off;
-      const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
       if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl)) {
         pl.prim = (int)off;
         pl.hitType = 1;
       }
     }
+#endif
   };
   u64 mask;
   uint32_t cur;   // interior node: index | axis << 29
@@ -590,15 +628,20 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
   bool open = true;   // this lane still looks for an occluder
   u64 openMask = all; // ... and the wave's mask of such lanes
   auto leaf_test = [&](uint32_t off, u64 m) {
+    const ConstF4 t = tris + 3 * (size_t)off;
+    const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
+#ifndef LT_BRANCHY_PACKET_LEAF
+    const bool hit = intersect_triangle_packet<PROGRAM>(t0, t1, t2, ray, pl, ((m >> lane) & 1ull) != 0ull && open && (int)off != ign, (int)off);
+    open = open && !hit;
+#else
     if (((m >> lane) & 1ull) && open && (int)off != ign) {
-      const ConstF4 t = tris + 3 * (size_t)off;
-      const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
       if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl)) {
         pl.prim = (int)off;
         pl.hitType = 1;
         open = false;
       }
     }
+#endif
     openMask = __builtin_amdgcn_ballot_w64(open);
   };
   u64 mask;
@@ -767,12 +810,10 @@ template <int PROGRAM, class CFG>
 __device__ inline bool direct_light(const SceneDev& sc, const float* pr, int primIndex, float u, float v, float fx,
                                     float fy, float seedIndex, float seedU, float seedV, float normal_w, V4& position,
                                     V4& normal, float& ndotl, Stack<CFG::kDeep>& st, Counters& c) {
-  const V3 b = barycentrics(u, v);
-  const V3 p3 = bary3(pr + 0, pr + 3, pr + 6, b);
-  position = mk4(p3.x, p3.y, p3.z, 1.0f);
-  const V3 n3 = bary3(pr + 9, pr + 12, pr + 15, b);
-  normal = mk4(n3.x, n3.y, n3.z, normal_w);
-
+  // Order of evaluation (not of arithmetic: every value is the reference's): the light sample first -- three random() calls,
+  // i.e. three double-precision sin / fmod evaluations that want every register -- and only then the hit primitive's own
+  // positions and normals, fenced so that the compiler does not issue those loads ahead of the randoms and carry 19 floats
+  // through them in scratch memory.
   const float* lp = light_prim(sc, random_(fx, fy, seedIndex));
   float uvx = random_(fx, fy, seedU);
   float uvy = random_(fx, fy, seedV);
@@ -783,13 +824,24 @@ __device__ inline bool direct_light(const SceneDev& sc, const float* pr, int pri
   const V3 lb = barycentrics(uvx, uvy);
   const V3 l3 = bary3(lp + 0, lp + 3, lp + 6, lb);
   const V4 lightPosition = mk4(l3.x, l3.y, l3.z, 1.0f);
+  asm volatile("" ::: "memory");
+
+  const V3 b = barycentrics(u, v);
+  const V3 p3 = bary3(pr + 0, pr + 3, pr + 6, b);
+  position = mk4(p3.x, p3.y, p3.z, 1.0f);
+  const V3 n3 = bary3(pr + 9, pr + 12, pr + 15, b);
+  normal = mk4(n3.x, n3.y, n3.z, normal_w);
 
   const V4 toLight = normalize4<CFG::kDevLibm>(sub4(lightPosition, position));
   Hit spl{0, 0, (float)((double)distance4<CFG::kDevLibm>(position, lightPosition) - 0.01), 0.0f, 0.0f};
   const Ray shadowRay{position, toLight};
+  // (before the walk, not after it as acc.cl:277 has it: the value does not depend on the walk, and the nine normal floats need
+  // not stay in registers -- i.e. in scratch memory, 48 bytes per pixel and sample -- while it runs)
+  ndotl = dot4(toLight, normal);
+  asm volatile("" : "+v"(ndotl));   // (pins it here: left alone, the compiler sinks the interpolation of the normal behind the walk)
   if (CFG::kStats) c.shadow++;
   traverse<PROGRAM, CFG::kDeep, CFG::kStats, true>(sc, shadowRay, true, primIndex, spl, st, c);
-  ndotl = dot4(toLight, normal);
+  asm volatile("" ::: "memory");    // (what the caller reads of the primitive afterwards -- its material -- is fetched afterwards)
   return spl.hitType == 0;
 }
 
@@ -876,11 +928,11 @@ __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, fl
   }
   if (pl.hitType == 1) {
     const float* pr = prim_ptr(sc, pl.prim);
-    const Material* m = sc.mats + prim_material(pr);
     V4 position, normal;
     float ndotl;
     if (direct_light<PROGRAM, CFG>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u),
                                            0.0f, position, normal, ndotl, st, c)) {
+      const Material* m = sc.mats + prim_material(pr);
       out = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
     }
   }
