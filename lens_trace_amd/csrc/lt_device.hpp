@@ -24,6 +24,8 @@ typedef unsigned long long uint64_t;
 #define M_PI 3.14159265358979323846
 #endif
 
+#include "lt_walk_asm.hpp"
+
 namespace lt {
 
 constexpr int kBlock = 64;         // one wavefront per workgroup: a finished wave frees its LDS and wave slot at once
@@ -233,6 +235,32 @@ __device__ __forceinline__ bool intersect_triangle_packet(const float4 t0, const
   pl.prim = ok ? prim : pl.prim;
   pl.hitType = ok ? 1 : pl.hitType;
   return ok;
+}
+
+// ... and for the any-hit packet walk: the caller of a shadow ray reads nothing but "was anything accepted" (acc.cl:276), the
+// first accepted triangle ends the lane's walk, so `t < payload.t` is always a test against the ray's initial tmax and no
+// payload needs to be carried or updated at all.
+template <int PROGRAM>
+__device__ __forceinline__ bool intersect_triangle_anyhit(const float4 t0, const float4 t1, const float4 t2, const Ray& ray, float tmax,
+                                                          bool active) {
+  const V4 A = mk4(t0.x, t0.y, t0.z, 1.0f);
+  const V4 v0v1 = mk4(t0.w, t1.x, t1.y, 0.0f);
+  const V4 v0v2 = mk4(t1.z, t1.w, t2.x, 0.0f);
+  const V4 pvec = cross4(ray.d, v0v2);
+  const float det = dot4(v0v1, pvec);
+  const float eps = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
+                    : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
+  bool ok = active && !(__builtin_fabsf(det) < eps);
+  const float invDet = 1.0f / det;
+  const V4 tvec = sub4(ray.o, A);
+  const float u = dot4(tvec, pvec) * invDet;
+  ok = ok && !(u < 0.0f || u > 1.0f);
+  if (__builtin_amdgcn_ballot_w64(ok) == 0ull) return false;
+  const V4 qvec = cross4(tvec, v0v1);
+  const float v = dot4(ray.d, qvec) * invDet;
+  ok = ok && !(v < 0.0f || u + v > 1.0f);
+  const float tt = dot4(v0v2, qvec) * invDet;
+  return ok && (tt < tmax);
 }
 
 // The per-lane traversal stack: entries [0,kLdsStack) live in LDS (column `lane`, row stride kBlock, so
@@ -624,78 +652,84 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
   const ConstF4 pairs = (ConstF4)(unsigned long long)sc.pairs;
   const ConstF4 tris = (ConstF4)(unsigned long long)sc.tris;
   const int lane = (int)__lane_id();
-  const u64 all = __builtin_amdgcn_ballot_w64(true);
-  bool open = true;   // this lane still looks for an occluder
-  u64 openMask = all; // ... and the wave's mask of such lanes
+  const float tmax = pl.t;
+  // The only state a leaf test changes is the wave's mask of lanes that still look for an occluder: it lives in a scalar
+  // register pair, no payload travels through the loop (pl.hitType is set from it at the end; pl.prim / t / u / v keep their
+  // initial values: the callers read hitType only).
+  u64 openMask = __builtin_amdgcn_ballot_w64(true);
   auto leaf_test = [&](uint32_t off, u64 m) {
     const ConstF4 t = tris + 3 * (size_t)off;
     const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
-#ifndef LT_BRANCHY_PACKET_LEAF
-    const bool hit = intersect_triangle_packet<PROGRAM>(t0, t1, t2, ray, pl, ((m >> lane) & 1ull) != 0ull && open && (int)off != ign, (int)off);
-    open = open && !hit;
-#else
-    if (((m >> lane) & 1ull) && open && (int)off != ign) {
-      if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl)) {
-        pl.prim = (int)off;
-        pl.hitType = 1;
-        open = false;
-      }
+    const bool active = (((m & openMask) >> lane) & 1ull) != 0ull && (int)off != ign;
+    openMask &= ~__builtin_amdgcn_ballot_w64(intersect_triangle_anyhit<PROGRAM>(t0, t1, t2, ray, tmax, active));
+  };
+  auto walk = [&]() {
+    u64 mask;
+    uint32_t cur = 0u;
+    {
+      const F8v nd = *(ConstF8)(nodes);
+      mask = box_mask<NEG>(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz);
+      if (mask == 0ull) return;
+      const uint32_t meta = __float_as_uint(nd.s7);
+      if ((meta & 0xffffu) != 0u) { leaf_test(__float_as_uint(nd.s6), mask); return; }
+    }
+#ifndef LT_NO_ASM_WALKS
+    if constexpr (NEG >= 0) {
+      // everything below the root in hand-written, scalar-controlled form (lt_walk_asm.hpp)
+      const float epsBits = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
+                            : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
+      const uint32_t ldsBase = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)ldsWave;
+      openMask = packet_anyhit_walk<NEG>((const void*)sc.pairs, (const void*)sc.tris, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y,
+                                         ray.d.z, ray.d.w, tmax, ign, epsBits, ldsBase, mask, openMask);
+      return;
     }
 #endif
-    openMask = __builtin_amdgcn_ballot_w64(open);
-  };
-  u64 mask;
-  uint32_t cur = 0u;
-  {
-    const F8v nd = *(ConstF8)(nodes);
-    mask = box_mask<NEG>(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz);
-    if (mask == 0ull) return;
-    const uint32_t meta = __float_as_uint(nd.s7);
-    if ((meta & 0xffffu) != 0u) { leaf_test(__float_as_uint(nd.s6), mask); return; }
-  }
-  int sp = 0;
-  for (;;) {
-    const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));   // (the axis bits are not needed here)
-    const F16v pr = *(ConstF16)((const __attribute__((address_space(4))) char*)pairs + (ci << 6));
-    const u64 live = mask & openMask;
-    const u64 hmL = box_mask<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz) & live;
-    const u64 hmR = box_mask<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz) & live;
-    const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
-    // (lt_pair_kernel tags leaves: 0x80000000 | primitive offset; plain nested ifs keep the control flow on SCC branches)
-    if (hmL != 0ull) {
-      if ((int)refL < 0) {
-        leaf_test(refL & 0x7fffffffu, hmL);
-      } else {
-        if (hmR != 0ull) {
-          if ((int)refR < 0) {
-            leaf_test(refR & 0x7fffffffu, hmR);
-            if (openMask == 0ull) return;
-          } else {   // the right child waits
-            ldsWave[sp * kBlock + 0] = (int)refR;
-            ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmR;
-            ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmR >> 32);
-            sp++;
+    int sp = 0;
+    for (;;) {
+      const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));   // (the axis bits are not needed here)
+      const F16v pr = *(ConstF16)((const __attribute__((address_space(4))) char*)pairs + (ci << 6));
+      const u64 live = mask & openMask;
+      const u64 hmL = box_mask<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz) & live;
+      const u64 hmR = box_mask<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz) & live;
+      const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
+      // (lt_pair_kernel tags leaves: 0x80000000 | primitive offset; plain nested ifs keep the control flow on SCC branches)
+      if (hmL != 0ull) {
+        if ((int)refL < 0) {
+          leaf_test(refL & 0x7fffffffu, hmL);
+        } else {
+          if (hmR != 0ull) {
+            if ((int)refR < 0) {
+              leaf_test(refR & 0x7fffffffu, hmR);
+              if (openMask == 0ull) return;
+            } else {   // the right child waits
+              ldsWave[sp * kBlock + 0] = (int)refR;
+              ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmR;
+              ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmR >> 32);
+              sp++;
+            }
           }
+          cur = refL; mask = hmL;
+          continue;
         }
-        cur = refL; mask = hmL;
-        continue;
       }
-    }
-    if (hmR != 0ull) {
-      if ((int)refR < 0) {
-        leaf_test(refR & 0x7fffffffu, hmR);
-      } else {
-        if (openMask == 0ull) return;
-        cur = refR; mask = hmR;
-        continue;
+      if (hmR != 0ull) {
+        if ((int)refR < 0) {
+          leaf_test(refR & 0x7fffffffu, hmR);
+        } else {
+          if (openMask == 0ull) return;
+          cur = refR; mask = hmR;
+          continue;
+        }
       }
+      if (openMask == 0ull || sp == 0) return;   // every lane has its occluder, or nothing is left to visit
+      sp--;
+      cur = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 0]);
+      mask = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 1]) |
+             ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 2]) << 32);
     }
-    if (openMask == 0ull || sp == 0) return;   // every lane has its occluder, or nothing is left to visit
-    sp--;
-    cur = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 0]);
-    mask = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 1]) |
-           ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 2]) << 32);
-  }
+  };
+  walk();
+  pl.hitType = ((openMask >> lane) & 1ull) != 0ull ? pl.hitType : 1;
 }
 
 // Camera rays: packet traversal when the wave qualifies, the per-lane traversal otherwise.
