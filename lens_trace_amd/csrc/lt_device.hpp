@@ -576,6 +576,17 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
     if ((meta & 0xffffu) != 0u) { leaf_test(__float_as_uint(nd.s6), mask); return; }
     cur = ((meta >> 16) & 3u) << 29;
   }
+#ifndef LT_NO_ASM_WALKS
+  {
+    // everything below the root in hand-written, scalar-controlled form (lt_walk_asm.hpp)
+    const float eps = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
+                      : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
+    const uint32_t ldsBase = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)ldsWave;
+    packet_closest_walk<NEG>((const void*)sc.pairs, (const void*)sc.tris, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y, ray.d.z,
+                             ray.d.w, eps, ldsBase, cur, mask, pl.t, pl.u, pl.v, pl.prim, pl.hitType);
+    return;
+  }
+#endif
   int sp = 0;
   for (;;) {
     const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));
