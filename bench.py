@@ -110,6 +110,8 @@ def parse():
     ap.add_argument("--scene", default="wall", choices=["wall", "soup", "blob", "colonnade", "cornell"])
     ap.add_argument("--program", default="accumulator")
     ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--bvh", default="median", choices=["median", "sah"], help="split rule of the scene's BVH (same 32-byte node layout): "
+                    "the reference's median split (default, the headline) or this backend's binned SAH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-soup", action="store_true", help="skip the second figure (config 4's incoherent triangle-soup variant)")
     return ap.parse_args()
@@ -118,6 +120,7 @@ def parse():
 def build_scene(args):
     from lens_trace_amd import scene as sc
     from lens_trace_amd import synth
+    sc.default_bvh = sc.BVH_SAH if args.bvh == "sah" else sc.BVH_MEDIAN
     if args.scene == "wall":
         return synth.heightfield_wall(args.cells), "synthetic height-field wall"
     if args.scene == "soup":
@@ -174,6 +177,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     scene, scene_name = build_scene(args)
+    if args.bvh == "sah":
+        scene_name += " (binned-SAH BVH)"
     scene.validate()
     W, H, D = args.width, args.height, 3
     program = C.program_from_path(args.program)
@@ -281,7 +286,7 @@ def main():
                            scene_name, scene.n_prims, W, H, args.spp, args.program,
                            "whole image on 1 GPU" if world == 1 else "%dx%d tiles interleaved over %d GPUs + 1 RCCL gather" % (plan.tile_w, plan.tile_h, world)),
                        "workload_key": "%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program),   # (names the profiles/ summaries of this workload)
-                       "triangles": scene.n_prims, "bvh_nodes": scene.n_nodes, "width": W, "height": H, "spp": args.spp,
+                       "triangles": scene.n_prims, "bvh_nodes": scene.n_nodes, "bvh_split": args.bvh, "width": W, "height": H, "spp": args.spp,
                        "rays_per_frame": rays_total, "node_visits_per_ray": nodes_total / rays_total,
                        "tri_tests_per_ray": tris_total / rays_total, "kernel_only_mrays_per_s": round(rays_total * args.steps / kernel_s / 1e6, 2),
                        "frame_ms": round(ms_per_step, 3),

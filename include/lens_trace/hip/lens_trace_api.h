@@ -37,7 +37,10 @@ enum StructureType {
 enum RenderPlatform { RENDER_PLATFORM_OPENCL, RENDER_PLATFORM_CUDA, RENDER_PLATFORM_OPTIX, RENDER_PLATFORM_HIP };
 enum KernelMode { KERNEL_MODE_LINEAR, KERNEL_MODE_TILE };
 enum ThreadOrganizationMode { THREAD_ORGANIZATION_MODE_MAX_FIT, THREAD_ORGANIZATION_MODE_CUSTOM };
-enum AccelerationStructureExplicitType { ACCELERATION_STRUCTURE_TYPE_BVH };
+// ..._BVH is the reference's builder (median split of the largest centroid extent, acceleration_structure_explicit.cpp:47-137);
+// ..._BVH_SAH is this backend's addition: binned surface-area-heuristic splits, SAME node / primitive / light layouts, one
+// triangle per leaf, height bounded (see scene_host.cpp) -- any renderer that reads the reference's buffers reads these.
+enum AccelerationStructureExplicitType { ACCELERATION_STRUCTURE_TYPE_BVH, ACCELERATION_STRUCTURE_TYPE_BVH_SAH };
 enum ImageType { IMAGE_TYPE_JPEG };
 
 struct AccelerationStructureExplicitProperties {

@@ -7,7 +7,7 @@
 //   output   { file_path }
 // with "RENDER_PLATFORM_HIP" as the platform (OPENCL / CUDA scene files are accepted too: their kernel_file_path selects the
 // built-in program by basename) and one optional extension object for the device-side progressive loop:
-//   hip { frame_first, frame_count, accumulate, gi_max_depth, device, portable_math }
+//   hip { frame_first, frame_count, accumulate, gi_max_depth, device, portable_math, bvh: "median" | "sah" }
 // Output: .jpg (the reference's format: ImageWriter, value*255 narrowed to 8 bits, quality 100; image_writer.cpp holds the
 // encoder), .pfm (float RGB, bottom-up as the format demands), .ppm (8-bit, same narrowing), .raw (the float buffer as is).
 // The JSON reader below is a ~100-line recursive-descent parser written for this file (objects, arrays, strings, numbers,
@@ -124,6 +124,7 @@ struct SceneConfig {   // defaults of the reference's SceneParser
   std::string outputPath = "output.jpg";
   uint32_t frameFirst = 0, frameCount = 0, accumulate = 0;
   int giMaxDepth = 0, device = 0;
+  bool sah = false;            // default: the reference's median-split builder
   bool portableMath = false;   // default: the reference kernels' own math on this GPU (BackendPropertiesHIP)
 };
 
@@ -162,6 +163,7 @@ bool loadScene(const std::string& path, SceneConfig& c, std::string& error) {
     c.frameCount = (uint32_t)num(h->find("frame_count"), 0);
     if (const Json* v = h->find("accumulate")) c.accumulate = v->kind == Json::Bool ? v->boolean : (v->number != 0);
     c.giMaxDepth = (int)num(h->find("gi_max_depth"), 0);
+    if (const Json* v = h->find("bvh")) c.sah = v->string == "sah";
     if (const Json* v = h->find("portable_math")) c.portableMath = v->kind == Json::Bool ? v->boolean : (v->number != 0);
     c.device = (int)num(h->find("device"), 0);
   }
@@ -240,7 +242,7 @@ int main(int argc, const char** argv) {
   if (!model->checkError()) return 1;
   AccelerationStructureExplicitProperties asp = {};
   asp.sType = STRUCTURE_TYPE_ACCELERATION_STRUCTURE_PROPERTIES;
-  asp.accelerationStructureExplicitType = ACCELERATION_STRUCTURE_TYPE_BVH;
+  asp.accelerationStructureExplicitType = cfg.sah ? ACCELERATION_STRUCTURE_TYPE_BVH_SAH : ACCELERATION_STRUCTURE_TYPE_BVH;
   asp.pModel = model.get();
   std::unique_ptr<AccelerationStructureExplicit> as(new AccelerationStructureExplicit(asp));
 

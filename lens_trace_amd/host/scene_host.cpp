@@ -288,9 +288,36 @@ struct BuildRange { int start, end, node, depth; };
 
 }  // namespace
 
-// Iterative median-split build straight into the flattened pre-order array: node i's left subtree starts at
-// i+1 and holds exactly 2*leftCount-1 nodes (every leaf is one triangle), so the right child's index is known
-// before either subtree is built.
+// Iterative build straight into the flattened pre-order array: node i's left subtree starts at i+1 and holds exactly
+// 2*leftCount-1 nodes (every leaf is one triangle), so the right child's index is known before either subtree is built --
+// whatever the split position, which is what lets the same loop serve both split rules:
+//   ACCELERATION_STRUCTURE_TYPE_BVH      median split of the largest centroid extent, the reference's rule
+//                                        (src/acceleration_structure_explicit.cpp:47-137, without its reads of uninitialised
+//                                        centroid bounds);
+//   ACCELERATION_STRUCTURE_TYPE_BVH_SAH  binned surface-area heuristic: 32 bins per axis over the centroid bounds, the split
+//                                        plane (over all three axes) that minimises area(L)*count(L) + area(R)*count(R).
+//                                        The traversal stack of the renderers is as deep as the tree is high (the reference's
+//                                        is a fixed 64, acc.cl:137; this backend sizes an LDS stack per launch), so the
+//                                        height is bounded: a subtree of k triangles at depth d must fit below
+//                                        ceil(log2 n) + kSahSlack levels, and a split that would not leave room falls back
+//                                        to the median.  Flatten order, axis field (the split axis, which the traversal
+//                                        uses for near / far), leaf = one triangle: as above.
+namespace {
+constexpr int kSahBins = 32;
+constexpr int kSahSlack = 4;
+
+int ceilLog2(int x) {
+  int l = 0;
+  while ((1 << l) < x) l++;
+  return l;
+}
+
+float halfArea(const float* lo, const float* hi) {
+  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+}  // namespace
+
 AccelerationStructureExplicit::AccelerationStructureExplicit(AccelerationStructureExplicitProperties properties) : height(0) {
   static_assert(sizeof(LinearBVHNode) == 32 && sizeof(Primitive) == 76 && sizeof(LightContainer) == 260 && sizeof(Material) == 32,
                 "buffer layouts are part of the renderer contract");
@@ -301,6 +328,8 @@ AccelerationStructureExplicit::AccelerationStructureExplicit(AccelerationStructu
   if (n == 0) return;
   const Material* materials = (const Material*)pModel->getMaterialBuffer();
   const uint64_t materialCount = pModel->getMaterialBufferSize() / sizeof(Material);
+  const bool sah = properties.accelerationStructureExplicitType == ACCELERATION_STRUCTURE_TYPE_BVH_SAH;
+  const int heightLimit = ceilLog2(n) + kSahSlack;
 
   std::vector<int> order(n);
   std::iota(order.begin(), order.end(), 0);
@@ -341,10 +370,64 @@ AccelerationStructureExplicit::AccelerationStructureExplicit(AccelerationStructu
     // then y over z when strictly larger)
     const float d[3] = {cmax[0] - cmin[0], cmax[1] - cmin[1], cmax[2] - cmin[2]};
     int dim = (d[0] > d[1] && d[0] > d[2]) ? 0 : (d[1] > d[2] ? 1 : 2);
-    const int mid = (r.start + r.end) / 2;
-    // coincident centroids on every axis (e.g. the two halves of a quad): still split, by input order, so that
-    // no leaf ever holds two triangles
-    if (d[dim] > 0.0f) {
+    int mid = (r.start + r.end) / 2;
+    bool split = false;
+    // a child of k triangles needs ceil(log2 k) more levels at least: both children must fit under the height limit
+    const int maxChild = (heightLimit - r.depth - 1) >= 30 ? count : std::min(count, 1 << std::max(0, heightLimit - r.depth - 1));
+    if (sah && count > 2 && maxChild >= (count + 1) / 2) {
+      float bestCost = std::numeric_limits<float>::max();
+      int bestDim = -1, bestBin = -1;
+      for (int a = 0; a < 3; a++) {
+        if (!(d[a] > 0.0f)) continue;
+        struct Bin { float lo[3], hi[3]; int count; } bins[kSahBins];
+        for (Bin& b : bins) {
+          for (int k = 0; k < 3; k++) { b.lo[k] = std::numeric_limits<float>::max(); b.hi[k] = -std::numeric_limits<float>::max(); }
+          b.count = 0;
+        }
+        const float scale = (float)kSahBins / d[a];
+        for (int i = r.start; i < r.end; i++) {
+          const PrimitiveInfo& p = prims[order[i]];
+          const int b = std::min(kSahBins - 1, std::max(0, (int)((p.centroid[a] - cmin[a]) * scale)));
+          bins[b].count++;
+          for (int k = 0; k < 3; k++) { bins[b].lo[k] = std::min(bins[b].lo[k], p.boundsMin[k]); bins[b].hi[k] = std::max(bins[b].hi[k], p.boundsMax[k]); }
+        }
+        // sweep: rightArea[b] = area of bins b..end
+        float rightArea[kSahBins];
+        int rightCount[kSahBins];
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::max(); hi[k] = -std::numeric_limits<float>::max(); }
+        int c = 0;
+        for (int b = kSahBins - 1; b >= 0; b--) {
+          if (bins[b].count) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], bins[b].lo[k]); hi[k] = std::max(hi[k], bins[b].hi[k]); }
+          c += bins[b].count;
+          rightCount[b] = c;
+          rightArea[b] = c ? halfArea(lo, hi) : 0.0f;
+        }
+        for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::max(); hi[k] = -std::numeric_limits<float>::max(); }
+        c = 0;
+        for (int b = 0; b + 1 < kSahBins; b++) {   // split after bin b
+          if (bins[b].count) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], bins[b].lo[k]); hi[k] = std::max(hi[k], bins[b].hi[k]); }
+          c += bins[b].count;
+          const int rc = rightCount[b + 1];
+          if (c == 0 || rc == 0 || c > maxChild || rc > maxChild) continue;
+          const float cost = halfArea(lo, hi) * (float)c + rightArea[b + 1] * (float)rc;
+          if (cost < bestCost) { bestCost = cost; bestDim = a; bestBin = b; }
+        }
+      }
+      if (bestDim >= 0) {
+        const float scale = (float)kSahBins / d[bestDim];
+        auto it = std::stable_partition(order.begin() + r.start, order.begin() + r.end, [&](int i) {
+          return std::min(kSahBins - 1, std::max(0, (int)((prims[i].centroid[bestDim] - cmin[bestDim]) * scale))) <= bestBin;
+        });
+        mid = (int)(it - order.begin());
+        dim = bestDim;
+        split = true;
+      }
+    }
+    // median split: the reference's rule, and the fallback of the SAH build (no plane separates the centroids, or the height
+    // limit leaves no room).  Coincident centroids on every axis (e.g. the two halves of a quad): still split, by input
+    // order, so that no leaf ever holds two triangles
+    if (!split && d[dim] > 0.0f) {
       std::nth_element(order.begin() + r.start, order.begin() + mid, order.begin() + r.end, [&](int a, int b) {
         const float ca = prims[a].centroid[dim], cb = prims[b].centroid[dim];
         return ca < cb || (ca == cb && a < b);   // total order: the build is deterministic
@@ -392,12 +475,12 @@ struct lt_host_scene {
   AccelerationStructureExplicit* as;
 };
 
-static lt_host_scene* finishScene(Model* m) {
+static lt_host_scene* finishScene(Model* m, int type = ACCELERATION_STRUCTURE_TYPE_BVH) {
   if (!m->checkError()) { delete m; return nullptr; }
   AccelerationStructureExplicitProperties props;
   props.sType = STRUCTURE_TYPE_ACCELERATION_STRUCTURE_PROPERTIES;
   props.pNext = nullptr;
-  props.accelerationStructureExplicitType = ACCELERATION_STRUCTURE_TYPE_BVH;
+  props.accelerationStructureExplicitType = type == ACCELERATION_STRUCTURE_TYPE_BVH_SAH ? ACCELERATION_STRUCTURE_TYPE_BVH_SAH : ACCELERATION_STRUCTURE_TYPE_BVH;
   props.pModel = m;
   lt_host_scene* s = new lt_host_scene;
   s->model = m;
@@ -410,6 +493,14 @@ lt_host_scene* lt_host_scene_from_obj(const char* path) { return finishScene(new
 lt_host_scene* lt_host_scene_from_triangles(const float* positions, const float* normals, const int* materialIndices,
                                             uint64_t triangleCount, const void* materials, uint64_t materialCount) {
   return finishScene(new Model(positions, normals, materialIndices, triangleCount, (const Material*)materials, materialCount));
+}
+
+// the same with the acceleration-structure type spelled out (ACCELERATION_STRUCTURE_TYPE_BVH = 0, ..._BVH_SAH = 1)
+lt_host_scene* lt_host_scene_from_obj_ex(const char* path, int type) { return finishScene(new Model(std::string(path)), type); }
+
+lt_host_scene* lt_host_scene_from_triangles_ex(const float* positions, const float* normals, const int* materialIndices,
+                                               uint64_t triangleCount, const void* materials, uint64_t materialCount, int type) {
+  return finishScene(new Model(positions, normals, materialIndices, triangleCount, (const Material*)materials, materialCount), type);
 }
 
 // which: 0 nodes, 1 ordered primitives, 2 materials, 3 light container

@@ -138,6 +138,10 @@ def _host_lib():
         L.lt_host_scene_from_obj.restype = vp
         L.lt_host_scene_from_triangles.argtypes = [vp, vp, vp, u64, vp, u64]
         L.lt_host_scene_from_triangles.restype = vp
+        L.lt_host_scene_from_obj_ex.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        L.lt_host_scene_from_obj_ex.restype = vp
+        L.lt_host_scene_from_triangles_ex.argtypes = [vp, vp, vp, u64, vp, u64, ctypes.c_int]
+        L.lt_host_scene_from_triangles_ex.restype = vp
         L.lt_host_scene_buffer.argtypes = [vp, ctypes.c_int, ctypes.POINTER(u64)]
         L.lt_host_scene_buffer.restype = vp
         L.lt_host_scene_height.argtypes = [vp]
@@ -165,13 +169,19 @@ def _scene_from_handle(L, h, camera):
         L.lt_host_scene_free(h)
 
 
-def load_obj(path, camera=None):
+# AccelerationStructureExplicitType (include/lens_trace/hip/lens_trace_api.h): the reference's median split, or binned SAH
+BVH_MEDIAN, BVH_SAH = 0, 1
+# default split rule of build_from_triangles / load_obj and of the synthetic scenes built on them (bench.py --bvh sets it)
+default_bvh = BVH_MEDIAN
+
+
+def load_obj(path, camera=None, bvh=None):
     """Model(path) + AccelerationStructureExplicit, in this repository's own implementation."""
     L = _host_lib()
-    return _scene_from_handle(L, L.lt_host_scene_from_obj(str(path).encode()), camera)
+    return _scene_from_handle(L, L.lt_host_scene_from_obj_ex(str(path).encode(), default_bvh if bvh is None else bvh), camera)
 
 
-def build_from_triangles(positions, normals, material_indices, materials, camera=None):
+def build_from_triangles(positions, normals, material_indices, materials, camera=None, bvh=None):
     """positions, normals: float32 [N,3,3]; material_indices: int32 [N]; materials: MATERIAL_DTYPE [K]."""
     import ctypes
     L = _host_lib()
@@ -182,6 +192,6 @@ def build_from_triangles(positions, normals, material_indices, materials, camera
     if pos.shape != nrm.shape or mi.shape[0] != pos.shape[0]:
         raise ValueError("triangle arrays disagree in length")
     vp = ctypes.c_void_p
-    h = L.lt_host_scene_from_triangles(pos.ctypes.data_as(vp), nrm.ctypes.data_as(vp), mi.ctypes.data_as(vp), pos.shape[0],
-                                       mats.ctypes.data_as(vp), mats.size // 32)
+    h = L.lt_host_scene_from_triangles_ex(pos.ctypes.data_as(vp), nrm.ctypes.data_as(vp), mi.ctypes.data_as(vp), pos.shape[0],
+                                          mats.ctypes.data_as(vp), mats.size // 32, default_bvh if bvh is None else bvh)
     return _scene_from_handle(L, h, camera)

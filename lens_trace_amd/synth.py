@@ -34,7 +34,7 @@ def _grid_triangles(P, N):
     return pos.astype(np.float32), nrm.astype(np.float32)
 
 
-def heightfield_wall(cells=708, camera=None):
+def heightfield_wall(cells=708, camera=None, bvh=None):
     """Config 4: a cells x cells height-field wall over x in [-5,5], y in [-2.5,7.5] that fills the frame
     (2*cells^2 triangles: 708 -> 1 002 528) plus a 2-triangle light.  Closed-form sines, no RNG."""
     x = np.linspace(-5.0, 5.0, cells + 1)
@@ -54,10 +54,10 @@ def heightfield_wall(cells=708, camera=None):
     pos = np.concatenate([pos, lp])
     nrm = np.concatenate([nrm, ln])
     mi = np.concatenate([band.astype(np.int32), np.full(2, len(mats) - 1, dtype=np.int32)])
-    return build_from_triangles(pos, nrm, mi, mats, camera or camera_bytes(0.0, 2.5, -50.0))
+    return build_from_triangles(pos, nrm, mi, mats, camera or camera_bytes(0.0, 2.5, -50.0), bvh)
 
 
-def triangle_soup(count=1000000, seed=1, camera=None):
+def triangle_soup(count=1000000, seed=1, camera=None, bvh=None):
     """Config 4 variant with incoherent traversal: `count` small random triangles in a slab in front of a back
     wall, fixed seed."""
     rng = np.random.default_rng(seed)
@@ -74,10 +74,10 @@ def triangle_soup(count=1000000, seed=1, camera=None):
     mats = _materials([(0.8, 0.8, 0.8), (0.9, 0.3, 0.25), (0.3, 0.75, 0.35), (0.3, 0.4, 0.9)])
     mi = np.concatenate([rng.integers(0, 4, count).astype(np.int32), np.zeros(2, np.int32), np.full(2, len(mats) - 1, np.int32)])
     return build_from_triangles(np.concatenate([pos, wall_p, lp]), np.concatenate([nrm, wall_n, ln]), mi, mats,
-                                camera or camera_bytes(0.0, 2.5, -50.0))
+                                camera or camera_bytes(0.0, 2.5, -50.0), bvh)
 
 
-def blob_in_box(subdiv=5, camera=None):
+def blob_in_box(subdiv=5, camera=None, bvh=None):
     """Config 3: a displaced, subdivided sphere (20 * 4^subdiv... here a lat-long sphere of ~70 k triangles at the
     default) inside a 5-wall box with a 2-triangle light."""
     nu = nv = int(round(np.sqrt(70000 / 2)))                  # ~187 x 187 cells -> ~70 k triangles
@@ -110,10 +110,10 @@ def blob_in_box(subdiv=5, camera=None):
     mi = np.concatenate([np.full(pos.shape[0], 3, np.int32), np.int32([0, 0, 0, 0, 0, 0, 1, 1, 2, 2]),
                          np.full(2, len(mats) - 1, np.int32)])
     return build_from_triangles(np.concatenate([pos, wp, lp]), np.concatenate([nrm, wn, ln]), mi, mats,
-                                camera or camera_bytes(0.0, 2.5, -50.0))
+                                camera or camera_bytes(0.0, 2.5, -50.0), bvh)
 
 
-def colonnade(columns=14, segments=96, rings=40, camera=None):
+def colonnade(columns=14, segments=96, rings=40, camera=None, bvh=None):
     """Config 5: a Sponza-like hall (~250 k triangles at the defaults): two rows of fluted columns carrying arches,
     floor, back wall and ceiling strips, one 2-triangle light.  Closed form, no RNG."""
     parts_p, parts_n, parts_m = [], [], []
@@ -164,4 +164,4 @@ def colonnade(columns=14, segments=96, rings=40, camera=None):
     pos = np.concatenate(parts_p + [lp])
     nrm = np.concatenate(parts_n + [ln])
     mi = np.concatenate(parts_m + [np.full(2, len(mats) - 1, np.int32)])
-    return build_from_triangles(pos, nrm, mi, mats, camera or camera_bytes(0.0, 2.5, -50.0))
+    return build_from_triangles(pos, nrm, mi, mats, camera or camera_bytes(0.0, 2.5, -50.0), bvh)

@@ -139,3 +139,25 @@ def test_builder_tree_is_balanced_and_renders():
     img, st = po.render(s, s.camera, 64, 36, po.ACCUMULATOR, threads=4, want_stats=True)
     assert st["max_stack"] <= s.height
     assert (img.sum(axis=2) > 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("make", [lambda b: synth.heightfield_wall(64, bvh=b), lambda b: synth.blob_in_box(3, bvh=b),
+                                  lambda b: synth.triangle_soup(5000, bvh=b), lambda b: synth.colonnade(4, 24, 10, bvh=b)])
+def test_sah_builder_emits_the_same_layout_with_fewer_node_visits(make):
+    """ACCELERATION_STRUCTURE_TYPE_BVH_SAH (this backend's addition): same buffers contract, one triangle per
+    leaf, height bounded by ceil(log2 n) + 4, same triangles -- and the reference's traversal visits fewer nodes in it."""
+    med, sah = make(sc.BVH_MEDIAN).validate(), make(sc.BVH_SAH).validate()
+    check_bvh_contract(sah)
+    assert sah.n_prims == med.n_prims and sah.n_nodes == med.n_nodes
+    assert sah.height <= int(np.ceil(np.log2(sah.n_prims))) + 4 and sah.height <= 64
+    assert np.array_equal(sah.materials, med.materials) and sah.light_view[0]["count"] == med.light_view[0]["count"]
+    # the same set of triangles, in another order
+    key = lambda s: np.sort(np.ascontiguousarray(s.prims).reshape(-1, 76).copy().view("V76").reshape(-1))   # noqa: E731
+    assert np.array_equal(key(sah), key(med))
+    again = make(sc.BVH_SAH)
+    assert np.array_equal(sah.nodes, again.nodes) and np.array_equal(sah.prims, again.prims)     # deterministic
+    _, sm = po.render(med, med.camera, 64, 36, po.ACCUMULATOR, threads=4, want_stats=True)
+    img, ss = po.render(sah, sah.camera, 64, 36, po.ACCUMULATOR, threads=4, want_stats=True)
+    assert ss["max_stack"] <= sah.height
+    assert ss["node_visits"] < sm["node_visits"]
+    assert (img.sum(axis=2) > 0).mean() > 0.3
