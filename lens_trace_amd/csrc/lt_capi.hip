@@ -557,7 +557,16 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_giCtl, 0, kGiCtlWords * sizeof(uint32_t), s));
   const uint32_t resident = (uint32_t)ctx->cu_count * 4u * LT_GI_STAGE_WAVES;
   const uint32_t gridA = (uint32_t)std::min<uint64_t>((uint64_t)fp.totalSquares * fp.fusedFrames, resident);
-  hipLaunchKernelGGL((lt_gi_primary_kernel<CFG>), dim3(gridA), dim3(kBlock), lds, s, sc, fp, gp, queues);
+  // the primary stage's shadow rays are accumulator's (same light samples from the same camera hits): any-hit packets unless this
+  // scene's accumulator frames were timed faster per lane (render_on_stream) or LT_SHADOW_PACKETS says otherwise; the bounce
+  // stages' shadow rays start on scattered bounce hits and stay per lane
+  SceneDev scPrimary = sc;
+  {
+    const char* spe = getenv("LT_SHADOW_PACKETS");
+    const int timed = ctx->shadow_mode[LT_PROGRAM_ACCUMULATOR];
+    scPrimary.shadowPackets = (CFG::kDeep ? 0u : spe ? (atoi(spe) != 0 ? 1u : 0u) : (timed == 0 ? 0u : 1u));
+  }
+  hipLaunchKernelGGL((lt_gi_primary_kernel<CFG>), dim3(gridA), dim3(kBlock), lds, s, scPrimary, fp, gp, queues);
   LT_HIP_CHECK(ctx, hipGetLastError());
   launches++;
   for (int d = 0; d < fp.giMaxDepth; d++) {

@@ -37,7 +37,10 @@ constexpr int kQueueStride = 64;   // dwords between work counters: one 256-byte
 constexpr int kMaxStack = 64;      // the reference's nodesToVisit[64] (acc.cl:137)
 constexpr float kFltMax = 3.402823466e+38f;
 
-enum Program { kBasic = 0, kBasicLighting = 1, kAccumulator = 2, kGI = 3, kGI25 = 4, kCustom = 5, kUser = 1000 };
+enum Program { kBasic = 0, kBasicLighting = 1, kAccumulator = 2, kGI = 3, kGI25 = 4, kCustom = 5,
+               kGIPrimary = 6,   // the global-illumination programs' camera-ray stage (lt_gi_primary_kernel): kGI's arithmetic; its shadow
+                                 // rays start on camera hits, as coherent as accumulator's, and may walk as any-hit packets
+               kUser = 1000 };
 
 struct V4 { float x, y, z, w; };
 struct V3 { float x, y, z; };

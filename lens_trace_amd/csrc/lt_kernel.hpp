@@ -233,8 +233,8 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_primary_kerne
         const float* pr = prim_ptr(sc, pl.prim);
         const Material* m = sc.mats + prim_material(pr);
         float ndotl;
-        if (direct_light<kGI, CFG>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u), 1.0f, position,
-                                   normal, ndotl, st, c)) {
+        if (direct_light<kGIPrimary, CFG>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u), 1.0f, position,
+                                          normal, ndotl, st, c)) {
           direct = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
         }
         const V4 hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_(fx, fy, (float)(s + 3u)), random_(fx, fy, (float)(s + 4u)));

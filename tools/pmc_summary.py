@@ -12,7 +12,7 @@ for d in sys.argv[1:]:
             for row in csv.DictReader(fh):
                 acc[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, cs in acc.items():
-            if "lt_render" not in k:
+            if "lt_" not in k:
                 continue
             for c, v in sorted(cs.items()):
                 print("%-28s %-62s n=%-3d mean=%.6g" % (c, k, len(v), sum(v) / len(v)))
