@@ -111,7 +111,8 @@ struct lt_hip_context {
   uint32_t* d_queues = nullptr;      // persistent mode: 8 per-XCD work counters per launch of a call
   uint32_t queue_frames = 0;
   int shadow_mode[6] = {-1, -1, -1, -1, -1, -1};   // per built-in program: shadow rays as any-hit packets (1) or per lane (0); -1 = not timed yet
-  hipEvent_t cal_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t cal_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::map<std::vector<uint32_t>, int> shadow_modes;   // (program, W, H, tile geometry) -> the walk timed faster for it on the resident scene
   float* d_samples = nullptr;        // un-accumulated sample images of a fused multi-sample launch
   uint64_t d_samples_bytes = 0;
   uint32_t* d_order = nullptr;       // persistent mode: hand-out order of the squares (slow-path squares first), cached
@@ -463,6 +464,7 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
   memcpy(ctx->scene_sizes, sizes, sizeof(sizes));
   ctx->scene_uploads++;
   for (int& m : ctx->shadow_mode) m = -1;
+  ctx->shadow_modes.clear();
   return LT_OK;
 }
 
@@ -828,7 +830,15 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   // changing the result, and the faster walk kept.  LT_SHADOW_PACKETS=0/1 forces one (tests, A/B measurements).
   const char* spe = getenv("LT_SHADOW_PACKETS");
   const bool hasShadowRays = d->program == LT_PROGRAM_ACCUMULATOR || d->program == LT_PROGRAM_BASIC_LIGHTING;   // (the GI programs' kernels hold the per-lane walk only)
-  int shadowMode = spe ? (atoi(spe) != 0) : (hasShadowRays ? ctx->shadow_mode[d->program] : 0);
+  // (keyed on the image geometry too: how coherent a wavefront's 64 shadow rays are depends on how large its 8x8 pixels are in
+  // the scene; shadow_mode[program] keeps the most recent verdict for callers without a geometry of their own: the GI pipeline)
+  const std::vector<uint32_t> shadowKey = {(uint32_t)d->program, d->width, d->height, p.tileW, p.tileH, p.tileFirst, p.tileStride};
+  int shadowMode = 0;
+  if (spe) shadowMode = atoi(spe) != 0;
+  else if (hasShadowRays) {
+    auto it = ctx->shadow_modes.find(shadowKey);
+    shadowMode = it == ctx->shadow_modes.end() ? -1 : it->second;
+  }
   sc.shadowPackets = shadowMode > 0 ? 1u : 0u;
 
   FrameParams fp{};
@@ -921,14 +931,31 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         const hipFunction_t fn = devlibm ? (deep ? up.deep : up.lds) : (deep ? up.deepPortable : up.ldsPortable);
         LT_HIP_CHECK(ctx, hipModuleLaunchKernel(fn, grid.x, 1, 1, kBlock, 1, 1, lds, s, args, nullptr));
       } else {
-        // time both shadow-ray walks once per (scene, program): only on a launch that can run twice (it overwrites its output)
+        // Time both shadow-ray walks once per (scene, program, image geometry), on a launch that can be repeated (it overwrites
+        // its output): the launch runs FOUR times -- packets, per lane, packets, per lane -- and each walk is given the faster
+        // of its two runs, so the first, cache-cold launch of a scene and a one-off hiccup decide nothing.  The last run is
+        // repeated with the winner only if the winner is not the walk that ran last.
         const bool calibrate = shadowMode < 0 && persistent && !stats && ctx->bvh_height <= kLdsStack && fp.accumulateN < 0;
-        for (int pass = 0; pass < (calibrate ? 2 : 1); pass++) {
+        const int passes = calibrate ? 4 : 1;
+        for (int pass = 0; pass < passes + (calibrate ? 1 : 0); pass++) {
           if (calibrate) {
             for (hipEvent_t& e : ctx->cal_ev) if (!e) LT_HIP_CHECK(ctx, hipEventCreate(&e));
-            sc.shadowPackets = pass == 0 ? 1u : 0u;   // packets first: the cold first launch of a scene counts against them
-            if (pass == 1) LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
-            LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass], s));
+            if (pass == passes) {   // all four are timed: decide; one more launch only if the per-lane walk (which ran last) lost
+              float t[4];
+              LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->cal_ev[7]));
+              for (int k = 0; k < 4; k++) LT_HIP_CHECK(ctx, hipEventElapsedTime(&t[k], ctx->cal_ev[2 * k], ctx->cal_ev[2 * k + 1]));
+              const float packets = std::min(t[0], t[2]), perLane = std::min(t[1], t[3]);
+              shadowMode = packets < 0.99f * perLane ? 1 : 0;   // (a tie keeps the per-lane walk)
+              ctx->shadow_modes[shadowKey] = shadowMode;
+              ctx->shadow_mode[d->program] = shadowMode;
+              sc.shadowPackets = (uint32_t)shadowMode;
+              launches += 3;
+              if (shadowMode == 0) break;
+            } else {
+              sc.shadowPackets = (pass & 1) ? 0u : 1u;
+            }
+            if (pass > 0) LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
+            if (pass < passes) LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass], s));
           }
           switch (d->program) {
         case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
@@ -938,17 +965,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
         default: launch_program<kCustom>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
           }
-          if (calibrate) LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass + 1], s));
-        }
-        if (calibrate) {
-          float perLane = 0.0f, packets = 0.0f;
-          LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->cal_ev[3]));
-          LT_HIP_CHECK(ctx, hipEventElapsedTime(&packets, ctx->cal_ev[0], ctx->cal_ev[1]));
-          LT_HIP_CHECK(ctx, hipEventElapsedTime(&perLane, ctx->cal_ev[2], ctx->cal_ev[3]));
-          shadowMode = packets < 0.97f * perLane ? 1 : 0;   // (a tie keeps the per-lane walk)
-          ctx->shadow_mode[d->program] = shadowMode;
-          sc.shadowPackets = (uint32_t)shadowMode;
-          launches++;
+          if (calibrate && pass < passes) LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass + 1], s));
+          if (calibrate && pass == passes) launches++;
         }
       }
       LT_HIP_CHECK(ctx, hipGetLastError());
