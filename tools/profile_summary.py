@@ -27,7 +27,12 @@ def counters(name):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, cs in acc.items():
+        dispatches[k] = max(dispatches.get(k, 0), max(len(v) for v in cs.values()))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+dispatches = {}
 
 
 def dominant(per_kernel, counter):
@@ -37,8 +42,8 @@ def dominant(per_kernel, counter):
         m = re.search(r"Config<(\w+), (\w+), (\w+)>", k)
         if "lt_" not in k or (m and m.group(2) == "true"):   # (Config<DEEP, STATS, DEVLIBM>: skip the counting instantiations)
             continue
-        if counter in cs and (best is None or cs[counter] > per_kernel[best][counter]):
-            best = k
+        if counter in cs and (best is None or cs[counter] * dispatches.get(k, 1) > per_kernel[best][counter] * dispatches.get(best, 1)):
+            best = k      # (the largest TOTAL over the run: mean per dispatch x dispatches)
     return best
 
 
@@ -71,56 +76,75 @@ if kern in passes["fetch"] and kern in passes["write"]:
     json.dump(hbm, open(os.path.join(out_dir, "hbm_traffic.json"), "w"), indent=1)
     print("hbm_traffic.json:", hbm["hbm_bytes_per_launch"] / 1e9, "GB per launch")
 
-c = {}
-for n in ("issue", "pipes", "insts", "sqc", "cache"):
-    c.update(passes[n].get(kern, {}))
-if "SQ_WAVE_CYCLES" in c:
-    CUS, SIMDS = 256, 1024
-    # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants); GRBM_GUI_ACTIVE is
-    # summed over the 8 XCDs
-    cycles = c.get("GRBM_GUI_ACTIVE", 0) / 8.0
-    if not cycles and ms:
-        cycles = ms * 1e-3 * 2.4e9
-    wave_quads = c["SQ_WAVE_CYCLES"]
-    prof = {"command": command, "kernel": kern, "workload": key, "launch_ms_under_profiler": ms, "shader_cycles_per_launch": cycles,
-            "effective_clock_ghz": (cycles / (ms * 1e-3) / 1e9) if ms else None, "raw": c}
-    frac = lambda x: (c[x] / wave_quads) if x in c else None
-    prof["wave_cycle_split"] = {"waiting_on_memory_or_barrier (SQ_WAIT_ANY)": frac("SQ_WAIT_ANY"),
-                                "issue_stalled (SQ_WAIT_INST_ANY)": frac("SQ_WAIT_INST_ANY"),
-                                "executing (SQ_ACTIVE_INST_ANY)": frac("SQ_ACTIVE_INST_ANY")}
-    if cycles:
-        pipes = {}
-        if "SQ_INSTS_VALU" in c:
-            pipes["valu"] = {"wave_instructions_per_simd_cycle": c["SQ_INSTS_VALU"] / SIMDS / cycles, "peak": 0.5,
-                             "frac": c["SQ_INSTS_VALU"] / SIMDS / cycles / 0.5}
-        if "SQ_INSTS_SALU" in c:
-            n = c["SQ_INSTS_SALU"] + c.get("SQ_INSTS_SMEM", 0.0)
-            pipes["scalar"] = {"instructions_per_cu_cycle (SALU + SMEM)": n / CUS / cycles, "peak": 1.0, "frac": n / CUS / cycles,
-                               "salu_only_frac": c["SQ_INSTS_SALU"] / CUS / cycles}
-        if "SQ_INSTS_VMEM_RD" in c:
-            pipes["vmem"] = {"instructions_per_cu_cycle": (c["SQ_INSTS_VMEM_RD"] + c.get("SQ_INSTS_VMEM_WR", 0)) / CUS / cycles}
-        if "SQ_INSTS_LDS" in c:
-            pipes["lds"] = {"instructions_per_cu_cycle": c["SQ_INSTS_LDS"] / CUS / cycles}
-        if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
-            pipes["valu"]["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
-        if "TA_BUSY_avr" in c:
-            pipes["texture_addresser_busy"] = c["TA_BUSY_avr"] / cycles
-        prof["pipes"] = pipes
-    if "SQC_ICACHE_REQ" in c:
-        prof["instruction_cache"] = {"requests": c["SQC_ICACHE_REQ"], "hit_rate": c["SQC_ICACHE_HITS"] / max(c["SQC_ICACHE_REQ"], 1.0),
-                                     "misses": c["SQC_ICACHE_MISSES"], "misses_per_1000_instructions":
-                                         1000.0 * c["SQC_ICACHE_MISSES"] / max(c.get("SQ_INSTS_VALU", 0) + c.get("SQ_INSTS_SALU", 0), 1.0)}
-    if "SQC_DCACHE_REQ" in c:
-        prof["scalar_cache"] = {"requests": c["SQC_DCACHE_REQ"], "hit_rate": c["SQC_DCACHE_HITS"] / max(c["SQC_DCACHE_REQ"], 1.0),
-                                "misses": c["SQC_DCACHE_MISSES"]}
-    if "TCC_HIT_sum" in c:
-        prof["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0)
-    if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
-        prof["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / max(c["TCP_TOTAL_CACHE_ACCESSES_sum"], 1.0)
-    # the binding class: the busiest issue pipe, unless the waves spend most of their cycles parked on memory
-    cand = {k: v["frac"] for k, v in prof.get("pipes", {}).items() if isinstance(v, dict) and "frac" in v}
-    if cand:
-        top = max(cand, key=cand.get)
-        prof["bound"] = {"class": {"valu": "valu-issue", "scalar": "scalar-issue"}[top], "frac": cand[top], "all": cand}
+def profile_of(kern):
+    c = {}
+    for n in ("issue", "pipes", "insts", "sqc", "cache"):
+        c.update(passes[n].get(kern, {}))
+    if "SQ_WAVE_CYCLES" not in c:
+        return None
+    ms = dur_ms.get(kern, (None, 0))[0]
+    if True:
+        CUS, SIMDS = 256, 1024
+        # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants); GRBM_GUI_ACTIVE is
+        # summed over the 8 XCDs
+        cycles = c.get("GRBM_GUI_ACTIVE", 0) / 8.0
+        if not cycles and ms:
+            cycles = ms * 1e-3 * 2.4e9
+        wave_quads = c["SQ_WAVE_CYCLES"]
+        prof = {"command": command, "kernel": kern, "workload": key, "launch_ms_under_profiler": ms, "shader_cycles_per_launch": cycles,
+                "effective_clock_ghz": (cycles / (ms * 1e-3) / 1e9) if ms else None, "raw": c}
+        frac = lambda x: (c[x] / wave_quads) if x in c else None
+        prof["wave_cycle_split"] = {"waiting_on_memory_or_barrier (SQ_WAIT_ANY)": frac("SQ_WAIT_ANY"),
+                                    "issue_stalled (SQ_WAIT_INST_ANY)": frac("SQ_WAIT_INST_ANY"),
+                                    "executing (SQ_ACTIVE_INST_ANY)": frac("SQ_ACTIVE_INST_ANY")}
+        if cycles:
+            pipes = {}
+            if "SQ_INSTS_VALU" in c:
+                pipes["valu"] = {"wave_instructions_per_simd_cycle": c["SQ_INSTS_VALU"] / SIMDS / cycles, "peak": 0.5,
+                                 "frac": c["SQ_INSTS_VALU"] / SIMDS / cycles / 0.5}
+            if "SQ_INSTS_SALU" in c:
+                n = c["SQ_INSTS_SALU"] + c.get("SQ_INSTS_SMEM", 0.0)
+                pipes["scalar"] = {"instructions_per_cu_cycle (SALU + SMEM)": n / CUS / cycles, "peak": 1.0, "frac": n / CUS / cycles,
+                                   "salu_only_frac": c["SQ_INSTS_SALU"] / CUS / cycles}
+            if "SQ_INSTS_VMEM_RD" in c:
+                pipes["vmem"] = {"instructions_per_cu_cycle": (c["SQ_INSTS_VMEM_RD"] + c.get("SQ_INSTS_VMEM_WR", 0)) / CUS / cycles}
+            if "SQ_INSTS_LDS" in c:
+                pipes["lds"] = {"instructions_per_cu_cycle": c["SQ_INSTS_LDS"] / CUS / cycles}
+            if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+                pipes["valu"]["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+            if "TA_BUSY_avr" in c:
+                pipes["texture_addresser_busy"] = c["TA_BUSY_avr"] / cycles
+            prof["pipes"] = pipes
+        if "SQC_ICACHE_REQ" in c:
+            prof["instruction_cache"] = {"requests": c["SQC_ICACHE_REQ"], "hit_rate": c["SQC_ICACHE_HITS"] / max(c["SQC_ICACHE_REQ"], 1.0),
+                                         "misses": c["SQC_ICACHE_MISSES"], "misses_per_1000_instructions":
+                                             1000.0 * c["SQC_ICACHE_MISSES"] / max(c.get("SQ_INSTS_VALU", 0) + c.get("SQ_INSTS_SALU", 0), 1.0)}
+        if "SQC_DCACHE_REQ" in c:
+            prof["scalar_cache"] = {"requests": c["SQC_DCACHE_REQ"], "hit_rate": c["SQC_DCACHE_HITS"] / max(c["SQC_DCACHE_REQ"], 1.0),
+                                    "misses": c["SQC_DCACHE_MISSES"]}
+        if "TCC_HIT_sum" in c:
+            prof["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0)
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+            prof["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / max(c["TCP_TOTAL_CACHE_ACCESSES_sum"], 1.0)
+        # the binding class: the busiest issue pipe, unless the waves spend most of their cycles parked on memory
+        cand = {k: v["frac"] for k, v in prof.get("pipes", {}).items() if isinstance(v, dict) and "frac" in v}
+        if cand:
+            top = max(cand, key=cand.get)
+            prof["bound"] = {"class": {"valu": "valu-issue", "scalar": "scalar-issue"}[top], "frac": cand[top], "all": cand}
+        prof["dispatches_profiled"] = dispatches.get(kern)
+        return prof
+
+
+prof = profile_of(kern)
+if prof:
+    # every other lt_ kernel of the run beside the dominant one (the stage kernels of the GI pipeline, the running mean, ...)
+    others = {}
+    for k in sorted(passes["issue"]):
+        if "lt_" in k and k != kern:
+            po = profile_of(k)
+            if po:
+                po.pop("raw", None)
+                others[k] = po
+    prof["other_kernels"] = others
     json.dump(prof, open(os.path.join(out_dir, "issue_profile.json"), "w"), indent=1)
-    print(json.dumps({k: v for k, v in prof.items() if k != "raw"}, indent=1))
+    print(json.dumps({k: v for k, v in prof.items() if k not in ("raw", "other_kernels")}, indent=1))
