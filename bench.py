@@ -48,7 +48,7 @@ def _latest_profile(name, workload_key):
     process: tools/collect_profiles.sh collects them for this same command in separate rocprofv3 passes)."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)) + glob.glob(os.path.join(ROOT, "profiles", "r*", "*", name))):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):

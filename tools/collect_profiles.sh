@@ -16,6 +16,7 @@ ROUND=${1:-r2}
 shift || true
 EXTRA="$@"
 OUT=gpurun_out/prof_$ROUND
+rm -rf "$OUT"      # (a pass directory must hold ONE run: the summaries average over every csv they find)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-soup $EXTRA"
@@ -36,6 +37,6 @@ pass sqc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_DCACHE_REQ SQC_DCA
 pass cache TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
 python3 tools/pmc_summary.py $OUT/fetch $OUT/write $OUT/issue $OUT/pipes $OUT/insts $OUT/sqc $OUT/cache > $OUT/pmc_summary.txt
 python3 tools/profile_summary.py $OUT "$B1" > $OUT/profile_summary.log 2>&1 || tail -5 $OUT/profile_summary.log
-tail -1 $OUT/stats.log > $OUT/bench_line_under_profiler.json
+grep '^{"metric"' $OUT/stats.log | tail -1 > $OUT/bench_line_under_profiler.json
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || true
 echo done

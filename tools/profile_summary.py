@@ -50,7 +50,7 @@ def dominant(per_kernel, counter):
 passes = {n: counters(n) for n in ("fetch", "write", "issue", "pipes", "insts", "sqc", "cache")}
 bench = {}
 try:
-    bench = json.loads(open(os.path.join(out_dir, "stats.log")).read().strip().splitlines()[-1])
+    bench = json.loads([ln for ln in open(os.path.join(out_dir, "stats.log")).read().splitlines() if ln.startswith('{"metric"')][-1])
 except Exception:
     pass
 
@@ -85,9 +85,12 @@ def profile_of(kern):
     ms = dur_ms.get(kern, (None, 0))[0]
     if True:
         CUS, SIMDS = 256, 1024
-        # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants); GRBM_GUI_ACTIVE is
-        # summed over the 8 XCDs
-        cycles = c.get("GRBM_GUI_ACTIVE", 0) / 8.0
+        # Shader cycles of one launch: SQ_BUSY_CYCLES is summed over the chip's 32 shader engines (MI355X_MICROARCH.md, chip-level
+        # parameters), so SQ_BUSY_CYCLES / 32 is the time the launch kept the shader busy, in shader clocks; divided by the
+        # launch's duration it gives the clock the chip held (2.36-2.39 GHz here).  (GRBM_GUI_ACTIVE / 8, the guide's DVFS
+        # recipe, reads ~25 % high on this persistent kernel under per-dispatch counter collection, so it is not used.)
+        # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants).
+        cycles = c.get("SQ_BUSY_CYCLES", 0) / 32.0
         if not cycles and ms:
             cycles = ms * 1e-3 * 2.4e9
         wave_quads = c["SQ_WAVE_CYCLES"]
