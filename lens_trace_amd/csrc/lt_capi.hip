@@ -571,8 +571,20 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   hipLaunchKernelGGL((lt_gi_primary_kernel<CFG>), dim3(gridA), dim3(kBlock), lds, s, scPrimary, fp, gp, queues);
   LT_HIP_CHECK(ctx, hipGetLastError());
   launches++;
+  // A scene of a few hundred triangles rides in LDS for the bounce stages' per-lane walks (Config::kLdsScene): workgroups of
+  // eight waves share one copy.  LT_GI_LDS_SCENE=0 turns it off (A/B measurements).
+  const uint64_t sceneLdsBytes = (uint64_t)ctx->n_nodes * 32 + (uint64_t)ctx->n_prims * 48;
+  const char* le = getenv("LT_GI_LDS_SCENE");
+  const bool ldsScene = !CFG::kDeep && sceneLdsBytes <= 16384 && !(le && atoi(le) == 0);
+  gp.ldsRows = lds / (kBlock * sizeof(int));
   for (int d = 0; d < fp.giMaxDepth; d++) {
-    hipLaunchKernelGGL((lt_gi_bounce_kernel<CFG>), dim3(resident), dim3(kBlock), lds, s, sc, fp, gp, (uint32_t)d);
+    if (ldsScene) {
+      using CFGL = Config<false, false, CFG::kDevLibm, true>;
+      hipLaunchKernelGGL((lt_gi_bounce_kernel<CFGL>), dim3((resident + kLdsSceneWaves - 1) / kLdsSceneWaves), dim3(kBlock * kLdsSceneWaves),
+                         (uint32_t)sceneLdsBytes + kLdsSceneWaves * lds, s, sc, fp, gp, (uint32_t)d);
+    } else {
+      hipLaunchKernelGGL((lt_gi_bounce_kernel<CFG>), dim3(resident), dim3(kBlock), lds, s, sc, fp, gp, (uint32_t)d);
+    }
     LT_HIP_CHECK(ctx, hipGetLastError());
     launches++;
   }

@@ -65,7 +65,17 @@ struct SceneDev {
   const Lights* lights;
   uint32_t n_nodes, n_prims, n_mats;
   uint32_t shadowPackets;   // != 0: shadow rays of the non-counting kernels walk as any-hit packets (chosen per scene by the host)
+  // A scene of a few hundred triangles (the Cornell box: 83 nodes + 42 triangles = 4.7 KB) lives in LDS for the per-lane walks of
+  // the kernels instantiated with Config::kLdsScene: byte offsets of the workgroup's copies of `nodes` and `tris` in its LDS
+  // (filled by the kernel itself, lt_kernel.hpp).  An incoherent per-lane walk is 64 distinct 32-byte fetches per visited node,
+  // and what saturates is the vector-memory address path (texture addresser 82 % busy on the Cornell box's bounce stage): LDS
+  // reads take that path out of the walk.
+  uint32_t ldsNodes, ldsTris;
 };
+
+typedef float LdsVec4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) LdsVec4* LdsF4;   // (a plain vector type: HIP's float4 class cannot be read through an address-space pointer)
+__device__ __forceinline__ float4 ld_lds(LdsF4 p) { const LdsVec4 v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 
 struct Counters {
   uint32_t rays, shadow, nodes, tris;
@@ -204,6 +214,11 @@ template <int PROGRAM>
 __device__ __forceinline__ bool intersect_triangle(const float4* __restrict__ tris, int prim, const Ray& ray, Hit& pl) {
   const float4* t = tris + 3 * (size_t)prim;
   return intersect_triangle_data<PROGRAM>(t[0], t[1], t[2], ray, pl);
+}
+template <int PROGRAM>
+__device__ __forceinline__ bool intersect_triangle_lds(uint32_t ldsTris, int prim, const Ray& ray, Hit& pl) {
+  const LdsF4 t = (LdsF4)(size_t)(ldsTris + 48u * (uint32_t)prim);
+  return intersect_triangle_data<PROGRAM>(ld_lds(t), ld_lds(t + 1), ld_lds(t + 2), ray, pl);
 }
 
 // The same test for the packet walks, where the triangle sits in SGPRs and the whole wave runs it anyway: no per-lane early
@@ -384,7 +399,7 @@ __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float 
 // ANYHIT (shadow rays, only when not counting work): the callers of a shadow ray read nothing but `hitType == 0`
 // (acc.cl:276, gi.cl:295,:351), so the walk may stop at the first accepted triangle -- same pixels, fewer node visits
 // than the reference algorithm performs.  The counting (STATS) instantiations never use it.
-template <int PROGRAM, bool DEEP, bool STATS, bool FINITE, bool ANYHIT>
+template <int PROGRAM, bool DEEP, bool STATS, bool FINITE, bool ANYHIT, bool LDSSCENE = false>
 __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool useIgnore, int ignore,
                                      Hit& pl, Stack<DEEP>& st, Counters& c) {
   const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
@@ -398,8 +413,14 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
   while (alive) {
     // 32-bit byte offset from the (wave-uniform) array base: lets the load use the SGPR-base + VGPR-offset form instead of
     // 64-bit address arithmetic on the node-to-node dependency chain (n_nodes * 32 < 2^32 is checked at set_scene)
-    const float4* n = (const float4*)((const char*)sc.nodes + ((uint32_t)cur << 5));
-    const float4 a = n[0], b = n[1];   // a = min.x min.y min.z max.x ; b = max.y max.z offset count|axis<<16
+    float4 a, b;   // a = min.x min.y min.z max.x ; b = max.y max.z offset count|axis<<16
+    if constexpr (LDSSCENE) {
+      const LdsF4 n = (LdsF4)(size_t)(sc.ldsNodes + ((uint32_t)cur << 5));
+      a = ld_lds(n); b = ld_lds(n + 1);
+    } else {
+      const float4* n = (const float4*)((const char*)sc.nodes + ((uint32_t)cur << 5));
+      a = n[0]; b = n[1];
+    }
     // the entry below the top is read now, beside the node fetch, whether or not this node turns out to need it
     const typename Stack<DEEP>::Pos below = st.below(sp);   // (the bottom row, unused, for a lane that is about to end)
     const int popped = st.load(below);
@@ -413,7 +434,7 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
     if (pend >= 0) {   // the leaf noted in the previous iteration
       LT_WAVE_COUNT(wTri);
       if (STATS) c.tris += pendCount;    // the reference *calls* intersectTriangle primitiveCount times
-      if (intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl)) {
+      if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl) : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl)) {
         pl.prim = pend;
         pl.hitType = 1;
         if (ANYHIT) return;
@@ -437,7 +458,7 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
   if (pend >= 0) {
     LT_WAVE_COUNT(wTri);
     if (STATS) c.tris += pendCount;
-    if (intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl)) {
+    if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl) : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl)) {
       pl.prim = pend;
       pl.hitType = 1;
     }
@@ -445,14 +466,15 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
 }
 
 // Compile-time configuration of one kernel instantiation.
-template <bool DEEP_, bool STATS_, bool DEVLIBM_>
+template <bool DEEP_, bool STATS_, bool DEVLIBM_, bool LDSSCENE_ = false>
 struct Config {
   static constexpr bool kDeep = DEEP_;       // BVH deeper than the LDS stack: spill entries >= kLdsStack to scratch
   static constexpr bool kStats = STATS_;     // count rays / node visits / triangle tests
   static constexpr bool kDevLibm = DEVLIBM_; // device-library leaf math (Math<true>)
+  static constexpr bool kLdsScene = LDSSCENE_; // the per-lane walks read nodes and triangles from the workgroup's LDS copy (SceneDev::ldsNodes)
 };
 
-template <int PROGRAM, bool DEEP, bool STATS, bool SHADOW>
+template <int PROGRAM, bool DEEP, bool STATS, bool SHADOW, bool LDSSCENE = false>
 __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgnore, int ignore, Hit& pl, Stack<DEEP>& st, Counters& c);
 
 // ---------------------------------------------------------------- packet traversal (camera rays)
@@ -785,7 +807,7 @@ __device__ inline void traverse_camera(const SceneDev& sc, const Ray& ray, Hit& 
   }
 }
 
-template <int PROGRAM, bool DEEP, bool STATS, bool SHADOW>
+template <int PROGRAM, bool DEEP, bool STATS, bool SHADOW, bool LDSSCENE>
 __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgnore, int ignore, Hit& pl,
                                 Stack<DEEP>& st, Counters& c) {
   constexpr bool ANYHIT = SHADOW && !STATS;
@@ -820,9 +842,9 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
       traverse_packet_pairs_anyhit<PROGRAM>(sc, ray, ix, iy, iz, ign, pl, row);
       return;
     }
-    traverse_nodes_impl<PROGRAM, DEEP, STATS, true, ANYHIT>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
+    traverse_nodes_impl<PROGRAM, DEEP, STATS, true, ANYHIT, LDSSCENE>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
   } else {   // e.g. the image-centre column/row, where a direction component is exactly 0
-    traverse_nodes_impl<PROGRAM, DEEP, STATS, false, ANYHIT>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
+    traverse_nodes_impl<PROGRAM, DEEP, STATS, false, ANYHIT, LDSSCENE>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
   }
 }
 
@@ -888,7 +910,7 @@ __device__ inline bool direct_light(const SceneDev& sc, const float* pr, int pri
   ndotl = dot4(toLight, normal);
   asm volatile("" : "+v"(ndotl));   // (pins it here: left alone, the compiler sinks the interpolation of the normal behind the walk)
   if (CFG::kStats) c.shadow++;
-  traverse<PROGRAM, CFG::kDeep, CFG::kStats, true>(sc, shadowRay, true, primIndex, spl, st, c);
+  traverse<PROGRAM, CFG::kDeep, CFG::kStats, true, CFG::kLdsScene>(sc, shadowRay, true, primIndex, spl, st, c);
   asm volatile("" ::: "memory");    // (what the caller reads of the primitive afterwards -- its material -- is fetched afterwards)
   return spl.hitType == 0;
 }

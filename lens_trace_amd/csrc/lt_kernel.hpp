@@ -171,6 +171,7 @@ struct GiParams {
   // samples k of one frame): frame f uses sample + f, its pixels live at [f * pixels, (f + 1) * pixels) of direct / indirect,
   // and every path carries its frame (m.w).
   uint32_t pixels;         // compact output pixels of one frame
+  uint32_t ldsRows;        // rows of each wave's LDS stack (the stage kernels with several waves per workgroup need it)
 };
 
 __device__ __forceinline__ bool square_pixel(const FrameParams& fp, uint32_t b, uint32_t& x, uint32_t& y, uint32_t& pix) {
@@ -255,21 +256,45 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_primary_kerne
   }
 }
 
+// Workgroup of the kLdsScene instantiations: eight wavefronts share one LDS copy of the scene (a 4.7 KB Cornell box + eight
+// 2 KB stacks = 21 KB per workgroup: the CU still holds its 32 waves).
+constexpr int kLdsSceneWaves = 8;
+
+// The workgroup's LDS: [scene copy (kLdsScene only): nodes, then traversal triangles][one stack of gp.ldsRows rows per wave].
+// Copies the scene (all threads, then a barrier) and returns this thread's stack column.
 template <class CFG>
-__global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_bounce_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t depth) {
+__device__ __forceinline__ int* stage_lds_setup(SceneDev& sc, uint32_t ldsRows, int* lds) {
+  uint32_t stackBase = 0;   // dwords
+  if constexpr (CFG::kLdsScene) {
+    const uint32_t nodeF4 = sc.n_nodes * 2u, triF4 = sc.n_prims * 3u;
+    float4* dst = (float4*)lds;
+    for (uint32_t i = threadIdx.x; i < nodeF4; i += blockDim.x) dst[i] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < triF4; i += blockDim.x) dst[nodeF4 + i] = sc.tris[i];
+    __syncthreads();
+    sc.ldsNodes = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)lds;
+    sc.ldsTris = sc.ldsNodes + nodeF4 * 16u;
+    stackBase = (nodeF4 + triF4) * 4u;
+  }
+  return lds + stackBase + (threadIdx.x / kBlock) * ldsRows * kBlock + (threadIdx.x % kBlock);
+}
+
+template <class CFG>
+__global__ __launch_bounds__(CFG::kLdsScene ? kBlock * kLdsSceneWaves : kBlock, LT_GI_STAGE_WAVES)
+void lt_gi_bounce_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t depth) {
   extern __shared__ int lds_stack[];
   Stack<CFG::kDeep> st;
-  st.lds = lds_stack + threadIdx.x;
+  st.lds = stage_lds_setup<CFG>(sc, gp.ldsRows, lds_stack);
   Counters c{};
   const GiQueue in = gp.q[depth & 1u], out = gp.q[(depth + 1u) & 1u];
   const uint32_t total = gp.counts[depth * kQueueStride];
   const int d = (int)depth;
+  const uint32_t lane = threadIdx.x % kBlock;
   for (;;) {
     uint32_t chunk = 0;
-    if (threadIdx.x == 0) chunk = atomicAdd(&gp.work[depth * kQueueStride], 1u);
+    if (lane == 0) chunk = atomicAdd(&gp.work[depth * kQueueStride], 1u);
     chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
     if ((uint64_t)chunk * kBlock >= total) break;
-    const uint32_t e = chunk * kBlock + threadIdx.x;
+    const uint32_t e = chunk * kBlock + lane;
     bool alive = false;
     V4 epos{}, enorm{}, ndir{};
     uint4 misc = make_uint4(0u, 0u, 0u, 0u);
@@ -284,7 +309,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_bounce_kernel
       const Ray ext{mk4(o.x, o.y, o.z, 1.0f), mk4(dd.x, dd.y, dd.z, dd.w)};
       const V4 previousNormal = mk4(nn.x, nn.y, nn.z, nn.w);
       Hit epl{0, 0, kFltMax, 0.0f, 0.0f};
-      traverse<kGI, CFG::kDeep, false, false>(sc, ext, true, (int)misc.y, epl, st, c);
+      traverse<kGI, CFG::kDeep, false, false, CFG::kLdsScene>(sc, ext, true, (int)misc.y, epl, st, c);
       const uint32_t s = gp.sample + misc.w, sd = s + depth;
       float4 ind = gp.indirect[pix];
       if (is_light(sc.lights, epl.prim)) {
