@@ -749,8 +749,12 @@ static int plan_fusion(lt_hip_context* ctx, const lt_hip_render_desc* d, const T
   // paths on small scenes).
   const char* ge = getenv("LT_GI_MEGAKERNEL");
   const bool giProgram = d->program == LT_PROGRAM_GLOBAL_ILLUMINATION || d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25;
-  const bool giManyLongPaths = giMaxDepth > 8 && (d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25 ||
-                                                    (d->program == LT_PROGRAM_GLOBAL_ILLUMINATION && frames > 1 && d->accumulate));
+  // (a scene small enough to ride in LDS through the bounce stages, launch_gi_sample, takes the pipeline from 2 bounces on:
+  // Cornell 1080p, 16 frames per call, 4 bounces: 8.6 against 10.9 ms; 25-sample variant 12.9 against 19.9 ms)
+  const bool ldsScene = ctx->bvh_height <= kLdsStack && (uint64_t)ctx->n_nodes * 32 + (uint64_t)ctx->n_prims * 48 <= 16384 &&
+                        !(getenv("LT_GI_LDS_SCENE") && atoi(getenv("LT_GI_LDS_SCENE")) == 0);
+  const bool giManyLongPaths = giMaxDepth > (ldsScene ? 1 : 8) && (d->program == LT_PROGRAM_GLOBAL_ILLUMINATION_25 ||
+                                                                   (d->program == LT_PROGRAM_GLOBAL_ILLUMINATION && frames > 1 && d->accumulate));
   const bool giWavefront = giProgram && !stats && nblocks > 0 && (ge ? atoi(ge) == 0 : (ctx->n_prims >= 1024u || giManyLongPaths));
   const uint64_t giPixels = (uint64_t)p.tilesInCall * p.tileW * p.tileH;
   if (giWavefront && giPixels > 0xffffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many pixels for the GI path queues");
