@@ -947,43 +947,45 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         const hipFunction_t fn = devlibm ? (deep ? up.deep : up.lds) : (deep ? up.deepPortable : up.ldsPortable);
         LT_HIP_CHECK(ctx, hipModuleLaunchKernel(fn, grid.x, 1, 1, kBlock, 1, 1, lds, s, args, nullptr));
       } else {
-        // Time both shadow-ray walks once per (scene, program, image geometry), on a launch that can be repeated (it overwrites
-        // its output): the launch runs FOUR times -- packets, per lane, packets, per lane -- and each walk is given the faster
-        // of its two runs, so the first, cache-cold launch of a scene and a one-off hiccup decide nothing.  The last run is
-        // repeated with the winner only if the winner is not the walk that ran last.
+        // Time both shadow-ray walks once per (scene, program, image geometry), ahead of a launch whose output they may scribble
+        // on (it overwrites what it writes, as every fused launch does): the launch's FIRST frame alone runs four times --
+        // packets, per lane, packets, per lane -- and each walk is given the faster of its two runs, so the first, cache-cold
+        // launch of a scene and a one-off hiccup decide nothing; then the launch itself runs once, with the winner.
         const bool calibrate = shadowMode < 0 && persistent && !stats && ctx->bvh_height <= kLdsStack && fp.accumulateN < 0;
-        const int passes = calibrate ? 4 : 1;
-        for (int pass = 0; pass < passes + (calibrate ? 1 : 0); pass++) {
-          if (calibrate) {
-            for (hipEvent_t& e : ctx->cal_ev) if (!e) LT_HIP_CHECK(ctx, hipEventCreate(&e));
-            if (pass == passes) {   // all four are timed: decide; one more launch only if the per-lane walk (which ran last) lost
-              float t[4];
-              LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->cal_ev[7]));
-              for (int k = 0; k < 4; k++) LT_HIP_CHECK(ctx, hipEventElapsedTime(&t[k], ctx->cal_ev[2 * k], ctx->cal_ev[2 * k + 1]));
-              const float packets = std::min(t[0], t[2]), perLane = std::min(t[1], t[3]);
-              shadowMode = packets < 0.99f * perLane ? 1 : 0;   // (a tie keeps the per-lane walk)
-              ctx->shadow_modes[shadowKey] = shadowMode;
-              ctx->shadow_mode[d->program] = shadowMode;
-              sc.shadowPackets = (uint32_t)shadowMode;
-              launches += 3;
-              if (shadowMode == 0) break;
-            } else {
-              sc.shadowPackets = (pass & 1) ? 0u : 1u;
-            }
-            if (pass > 0) LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
-            if (pass < passes) LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass], s));
-          }
+        auto launch_render = [&](const FrameParams& fpl, dim3 g) {
           switch (d->program) {
-        case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
-        case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
-        case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
-        case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
-        case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
-        default: launch_program<kCustom>(lc, grid, lds, s, sc, fp, out_launch, ctx->d_stats, queues); break;
+            case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            default: launch_program<kCustom>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
           }
-          if (calibrate && pass < passes) LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass + 1], s));
-          if (calibrate && pass == passes) launches++;
+        };
+        if (calibrate) {
+          for (hipEvent_t& e : ctx->cal_ev) if (!e) LT_HIP_CHECK(ctx, hipEventCreate(&e));
+          FrameParams f1 = fp;
+          f1.fusedFrames = 1;
+          const dim3 g1((uint32_t)std::min<uint64_t>(nblocks, resident));
+          for (int pass = 0; pass < 4; pass++) {
+            sc.shadowPackets = (pass & 1) ? 0u : 1u;
+            if (pass > 0) LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
+            LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass], s));
+            launch_render(f1, g1);
+            LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass + 1], s));
+          }
+          float t[4];
+          LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->cal_ev[7]));
+          for (int k = 0; k < 4; k++) LT_HIP_CHECK(ctx, hipEventElapsedTime(&t[k], ctx->cal_ev[2 * k], ctx->cal_ev[2 * k + 1]));
+          const float packets = std::min(t[0], t[2]), perLane = std::min(t[1], t[3]);
+          shadowMode = packets < 0.99f * perLane ? 1 : 0;   // (a tie keeps the per-lane walk)
+          ctx->shadow_modes[shadowKey] = shadowMode;
+          ctx->shadow_mode[d->program] = shadowMode;
+          sc.shadowPackets = (uint32_t)shadowMode;
+          launches += 4;
+          LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
         }
+        launch_render(fp, grid);
       }
       LT_HIP_CHECK(ctx, hipGetLastError());
       launches++;
