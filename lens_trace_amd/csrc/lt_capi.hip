@@ -449,7 +449,7 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
   hipLaunchKernelGGL(lt_retile_kernel, dim3((n_prims + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->d_prims,
                      (float4*)ctx->d_tris, n_prims);
   LT_HIP_CHECK(ctx, hipGetLastError());
-  if (n_nodes > 0x1fffffffu) return fail(ctx, LT_ERR_BAD_SCENE, "too many nodes for the child-pair records");
+  if ((uint64_t)n_nodes * 64 > 0xffffffffull) return fail(ctx, LT_ERR_BAD_SCENE, "too many nodes for the child-pair records (64 bytes each, 32-bit byte offsets)");
   LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pairs, (size_t)n_nodes * 64));
   hipLaunchKernelGGL(lt_pair_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes,
                      (float4*)ctx->d_pairs, n_nodes);
