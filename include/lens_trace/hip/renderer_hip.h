@@ -34,6 +34,10 @@ struct BackendPropertiesHIP {
   // this GPU -- render() is bit-identical to RendererOpenCL running the same kernel file on the MI355X.  1: the correctly
   // rounded forms every IEEE machine reproduces (what the CPU oracle computes; LT_RENDER_FLAG_PORTABLE_MATH).
   uint32_t portableMath;
+  // 1: the reference kernels as RendererOpenCL builds them -- clBuildProgram with NULL options: `a*b + c` of one source
+  // expression fused, float divide / sqrt at the OpenCL default accuracy -- bit for bit on this GPU (LT_RENDER_FLAG_AS_SHIPPED_MATH;
+  // excludes portableMath)
+  uint32_t asShippedMath;
   // Scene-change contract.  0 (default): every render() hashes the four scene buffers in full and re-uploads when anything
   // changed -- the reference's "upload on every call" semantics (renderer_opencl.cpp:107-120) at the price of one pass over
   // host memory (~20 ms for the 1 M-triangle scene).  != 0: the caller versions its scene -- the buffers are re-examined only

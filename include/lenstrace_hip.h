@@ -90,7 +90,13 @@ enum {
                                         Flag set: correctly rounded forms every IEEE machine reproduces -- what the CPU oracle
                                         computes; differs from the default by <= 1-2 ulp in those leaf functions, which the
                                         stochastic programs' random() can amplify into a flipped ray decision in ~0.03 % of
-                                        pixels. */
+                                        pixels. */,
+  LT_RENDER_FLAG_AS_SHIPPED_MATH = 16u /* The default flavour matches the reference kernels built with -ffp-contract=off
+                                        -cl-fp32-correctly-rounded-divide-sqrt.  This one matches them as RendererOpenCL builds
+                                        them -- clBuildProgram with NULL options (src/opencl/renderer_opencl.cpp:50): `a*b + c` of
+                                        one source expression fused, float divide / sqrt at the OpenCL default accuracy
+                                        (v_rcp_f32 / v_sqrt_f32 based) -- bit for bit on this GPU with this ROCm's OpenCL
+                                        compiler.  Not with the counter flags, not for user programs. */
 };
 
 typedef struct lt_hip_render_desc {

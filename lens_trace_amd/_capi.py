@@ -18,6 +18,7 @@ RENDER_FLAG_STATS = 1
 RENDER_FLAG_PIXEL_COUNTERS = 2
 RENDER_FLAG_DEVICE_LIBM = 4      # ignored since ABI 3 (it is the default flavour)
 RENDER_FLAG_PORTABLE_MATH = 8
+RENDER_FLAG_AS_SHIPPED_MATH = 16
 
 # every symbol include/lenstrace_hip.h declares
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",

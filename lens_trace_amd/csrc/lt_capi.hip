@@ -504,19 +504,21 @@ extern "C" int lt_hip_output_floats(const lt_hip_render_desc* desc, uint64_t* ou
   return LT_OK;
 }
 
-struct LaunchConfig { bool deep, stats, devlibm; };
+struct LaunchConfig { bool deep, stats; int devlibm; };   // devlibm: the math flavour, Math<0 / 1 / 2> (lt_device.hpp)
 
 template <int PROGRAM>
 static void launch_program(const LaunchConfig& k, dim3 grid, uint32_t lds, hipStream_t s, const SceneDev& sc, const FrameParams& fp,
                            float* out, unsigned long long* st, uint32_t* queues) {
 #define LT_LAUNCH(D, S, M) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, Config<D, S, M>>), grid, dim3(kBlock), lds, s, sc, fp, out, st, queues)
-  if (k.devlibm) {          // the default flavour: the OpenCL device library's leaf math (Math<true>)
-    if (k.deep) { if (k.stats) LT_LAUNCH(true, true, true); else LT_LAUNCH(true, false, true); }
-    else { if (k.stats) LT_LAUNCH(false, true, true); else LT_LAUNCH(false, false, true); }
+  if (k.devlibm == 2) {     // as shipped (no counting variant: render_on_stream refuses the combination)
+    if (k.deep) LT_LAUNCH(true, false, 2); else LT_LAUNCH(false, false, 2);
+  } else if (k.devlibm == 1) {   // the default flavour: the OpenCL device library's leaf math
+    if (k.deep) { if (k.stats) LT_LAUNCH(true, true, 1); else LT_LAUNCH(true, false, 1); }
+    else { if (k.stats) LT_LAUNCH(false, true, 1); else LT_LAUNCH(false, false, 1); }
   } else if (k.deep) {
-    if (k.stats) LT_LAUNCH(true, true, false); else LT_LAUNCH(true, false, false);
+    if (k.stats) LT_LAUNCH(true, true, 0); else LT_LAUNCH(true, false, 0);
   } else {
-    if (k.stats) LT_LAUNCH(false, true, false); else LT_LAUNCH(false, false, false);
+    if (k.stats) LT_LAUNCH(false, true, 0); else LT_LAUNCH(false, false, 0);
   }
 #undef LT_LAUNCH
 }
@@ -699,10 +701,10 @@ static int launch_gi_sets(lt_hip_context* ctx, hipStream_t s, const SceneDev& sc
       sample = fp.frameCount * 32u + k0;
     }
     int rc;
-    if (lc.deep) rc = lc.devlibm ? launch_gi_sample<Config<true, false, true>>(ctx, s, sc, fs, out, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches)
-                                 : launch_gi_sample<Config<true, false, false>>(ctx, s, sc, fs, out, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches);
-    else rc = lc.devlibm ? launch_gi_sample<Config<false, false, true>>(ctx, s, sc, fs, out, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches)
-                         : launch_gi_sample<Config<false, false, false>>(ctx, s, sc, fs, out, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches);
+#define LT_GI(D, M) launch_gi_sample<Config<D, false, M>>(ctx, s, sc, fs, out, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches)
+    if (lc.deep) rc = lc.devlibm == 2 ? LT_GI(true, 2) : lc.devlibm == 1 ? LT_GI(true, 1) : LT_GI(true, 0);
+    else rc = lc.devlibm == 2 ? LT_GI(false, 2) : lc.devlibm == 1 ? LT_GI(false, 1) : LT_GI(false, 0);
+#undef LT_GI
     if (rc) return rc;
   }
   return LT_OK;
@@ -856,6 +858,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
     shadowMode = it == ctx->shadow_modes.end() ? -1 : it->second;
   }
   sc.shadowPackets = shadowMode > 0 ? 1u : 0u;
+  sc.ldsNodes = sc.ldsTris = 0u;
+  sc.fastRcp = 0u;
 
   FrameParams fp{};
   fp.camx = cam[0]; fp.camy = cam[1]; fp.camz = cam[2];
@@ -877,7 +881,12 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   const bool deep = ctx->bvh_height > kLdsStack;
   // The default flavour is the one that is bit-identical to the reference's OpenCL kernels on this GPU (Math<true>);
   // LT_RENDER_FLAG_PORTABLE_MATH asks for the correctly rounded leaf functions the CPU oracle reproduces.
-  const bool devlibm = (d->flags & LT_RENDER_FLAG_PORTABLE_MATH) == 0;
+  if ((d->flags & LT_RENDER_FLAG_PORTABLE_MATH) && (d->flags & LT_RENDER_FLAG_AS_SHIPPED_MATH))
+    return fail(ctx, LT_ERR_INVALID_ARGUMENT, "LT_RENDER_FLAG_PORTABLE_MATH and LT_RENDER_FLAG_AS_SHIPPED_MATH exclude each other");
+  const int devlibm = (d->flags & LT_RENDER_FLAG_PORTABLE_MATH) ? 0 : (d->flags & LT_RENDER_FLAG_AS_SHIPPED_MATH) ? 2 : 1;
+  if (devlibm == 2 && (stats || userProgram))
+    return fail(ctx, LT_ERR_INVALID_ARGUMENT, "LT_RENDER_FLAG_AS_SHIPPED_MATH has no counting variant and no user-program variant");
+  sc.fastRcp = devlibm == 2 ? 1u : 0u;
   const LaunchConfig lc{deep, stats, devlibm};
   const uint32_t frames = d->frame_count ? d->frame_count : 1;
   const uint64_t nblocks = (uint64_t)p.tilesInCall * fp.blocksPerTile;

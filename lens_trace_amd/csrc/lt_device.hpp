@@ -71,6 +71,7 @@ struct SceneDev {
   // and what saturates is the vector-memory address path (texture addresser 82 % busy on the Cornell box's bounce stage): LDS
   // reads take that path out of the walk.
   uint32_t ldsNodes, ldsTris;
+  uint32_t fastRcp;         // != 0: intersectTriangle's 1 / det as the reference's as-shipped build computes it (Math<2>::rcp), in every walk
 };
 
 typedef float LdsVec4 __attribute__((ext_vector_type(4)));
@@ -105,13 +106,44 @@ __device__ __forceinline__ V4 cross4(V4 a, V4 b) {
              __builtin_fmaf(a.x, b.y, -(a.y * b.x)), 0.0f);
 }
 // The four leaf functions where ROCm's OpenCL device library uses a hardware approximation or its own float trig.
-//   Math<false> "portable": correctly rounded forms every IEEE machine reproduces -- the CPU oracle's definition.
-//   Math<true>  "device libm": what the reference's OpenCL kernels get on this GPU (read from their gfx950 ISA):
+//   Math<0> "portable": correctly rounded forms every IEEE machine reproduces -- the CPU oracle's definition.
+//   Math<1> "device libm": what the reference's OpenCL kernels get on this GPU (read from their gfx950 ISA):
 //       rsqrt  = v_rsq_f32 with the library's denormal pre-scale, sqrt (inside distance) = v_sqrt_f32 with the
 //       backend's denormal scaling, sin/cos(float) = ocml's, clamp = v_med3_f32.  With it the HIP path is
-//       bit-identical to the reference's own kernels compiled for gfx950 (tests/test_gpu_reference_kernels.py).
-template <bool DEVLIBM>
+//       bit-identical to the reference's own kernels compiled for gfx950 with -ffp-contract=off
+//       -cl-fp32-correctly-rounded-divide-sqrt (tests/test_gpu_reference_kernels.py).
+//   Math<2> "as shipped": Math<1> plus what clBuildProgram's NULL options (src/opencl/renderer_opencl.cpp:50) change in the
+//       reference's USER-level expressions on this GPU, read from the LLVM IR and ISA of that build of the six kernel files:
+//       * -ffp-contract=on: `a*b + c` inside ONE source expression is one fused multiply-add -- the left product when both
+//         addends are products (clang's rule).  Sites: the camera's yaw rotation, every barycentric interpolation
+//         A*b.x + B*b.y + C*b.z, random()'s dot + 1113.1*seed (in double), refract's two, 1 - z*z and the change of basis of
+//         the hemisphere sample, the `indirect +=` terms, the 25-sample blend.  mad() below.
+//       * float division and sqrt at the default 2.5 / 3 ulp: x / y = ldexp(frexp_mant(x) * v_rcp_f32(frexp_mant(y)),
+//         frexp_exp(x) - frexp_exp(y)) -- the film position x / width, 1 / det in intersectTriangle, (25 - k) / 25 --
+//         and v_sqrt_f32 with the backend's denormal scaling.  fdiv() / rcp() / sqrt_user() below.
+//       With it the HIP path is bit-identical to the reference's kernels as RendererOpenCL builds them.
+template <int DEVLIBM>
 struct Math {
+  static constexpr bool kShipped = DEVLIBM == 2;
+  static __device__ __forceinline__ float mad(float a, float b, float c) { return kShipped ? __builtin_fmaf(a, b, c) : a * b + c; }
+  static __device__ __forceinline__ double mad(double a, double b, double c) { return kShipped ? __builtin_fma(a, b, c) : a * b + c; }
+  static __device__ __forceinline__ float rcp(float x) {   // 1.0f / x
+    if (kShipped) return __builtin_amdgcn_ldexpf(__builtin_amdgcn_rcpf(__builtin_amdgcn_frexp_mantf(x)), -__builtin_amdgcn_frexp_expf(x));
+    return 1.0f / x;
+  }
+  static __device__ __forceinline__ float fdiv(float a, float b) {
+    if (kShipped)
+      return __builtin_amdgcn_ldexpf(__builtin_amdgcn_frexp_mantf(a) * __builtin_amdgcn_rcpf(__builtin_amdgcn_frexp_mantf(b)),
+                                     __builtin_amdgcn_frexp_expf(a) - __builtin_amdgcn_frexp_expf(b));
+    return a / b;
+  }
+  static __device__ __forceinline__ float sqrt_user(float x) { return kShipped ? sqrt_in_distance(x) : __builtin_sqrtf(x); }
+  // x / 25.0f (the 25-sample blend's attenuation): the constant's half of the fast division is folded at compile time in the
+  // reference build -- frexp_mant(25) = 0.78125, its reciprocal 1.28f = 0x3fa3d70a, frexp_exp(25) = 5
+  static __device__ __forceinline__ float div25(float x) {
+    if (kShipped) return __builtin_amdgcn_ldexpf(__builtin_amdgcn_frexp_mantf(x) * __uint_as_float(0x3fa3d70au), __builtin_amdgcn_frexp_expf(x) - 5);
+    return x / (float)25;
+  }
   static __device__ __forceinline__ float rsqrt(float x) {
     if (DEVLIBM) {
       const bool small = x < 1.17549435e-38f;
@@ -134,7 +166,7 @@ struct Math {
   }
 };
 
-template <bool DEVLIBM>
+template <int DEVLIBM>
 __device__ inline V4 normalize4(V4 p) {
   if (p.x == 0.0f && p.y == 0.0f && p.z == 0.0f && p.w == 0.0f) return p;
   float l2 = dot4(p, p);
@@ -153,7 +185,7 @@ __device__ inline V4 normalize4(V4 p) {
   return scale4(Math<DEVLIBM>::rsqrt(l2), p);
 }
 
-template <bool DEVLIBM>
+template <int DEVLIBM>
 __device__ inline float distance4(V4 a, V4 b) {
   V4 d = sub4(a, b);
   float l2 = dot4(d, d);
@@ -168,9 +200,10 @@ __device__ inline float distance4(V4 a, V4 b) {
 }
 
 // acc.cl:63-66: float dot, then double add / fmod / sin / mul, then float fract
+template <int M = 0>
 __device__ inline float random_(float uvx, float uvy, float seed) {
   float d = dot2(uvx, uvy, 12.9898f, 78.233f);
-  double x = (double)d + 1113.1 * (double)seed;
+  double x = Math<M>::kShipped ? __builtin_fma(1113.1, (double)seed, (double)d) : (double)d + 1113.1 * (double)seed;
   float a = (float)(sin(fmod(x, M_PI)) * 43758.5453);
   return a - __builtin_floorf(a);
 }
@@ -179,7 +212,7 @@ __device__ inline float random_(float uvx, float uvy, float seed) {
 // acc.cl:72-111 on the re-tiled triangle.  PROGRAM picks the epsilon flavour: basic.cl:78 compares in
 // float against 1e-7f, basic_lighting.cl:4 in double against 1e-7, the others in double against 1e-4.
 template <int PROGRAM>
-__device__ __forceinline__ bool intersect_triangle_data(const float4 t0, const float4 t1, const float4 t2, const Ray& ray, Hit& pl) {
+__device__ __forceinline__ bool intersect_triangle_data(const float4 t0, const float4 t1, const float4 t2, const Ray& ray, Hit& pl, bool fastRcp = false) {
   V4 A = mk4(t0.x, t0.y, t0.z, 1.0f);
   V4 v0v1 = mk4(t0.w, t1.x, t1.y, 0.0f);
   V4 v0v2 = mk4(t1.z, t1.w, t2.x, 0.0f);
@@ -195,7 +228,8 @@ __device__ __forceinline__ bool intersect_triangle_data(const float4 t0, const f
   } else {
     if (__builtin_fabsf(det) < __uint_as_float(0x38d1b718u)) return false;
   }
-  float invDet = 1.0f / det;
+  // (fastRcp: SceneDev::fastRcp, the as-shipped flavour's 1 / det -- Math<2>::rcp; wave-uniform)
+  float invDet = fastRcp ? Math<2>::rcp(det) : 1.0f / det;
   V4 tvec = sub4(ray.o, A);
   float u = dot4(tvec, pvec) * invDet;
   if (u < 0.0f || u > 1.0f) return false;
@@ -211,14 +245,14 @@ __device__ __forceinline__ bool intersect_triangle_data(const float4 t0, const f
 }
 
 template <int PROGRAM>
-__device__ __forceinline__ bool intersect_triangle(const float4* __restrict__ tris, int prim, const Ray& ray, Hit& pl) {
+__device__ __forceinline__ bool intersect_triangle(const float4* __restrict__ tris, int prim, const Ray& ray, Hit& pl, bool fastRcp = false) {
   const float4* t = tris + 3 * (size_t)prim;
-  return intersect_triangle_data<PROGRAM>(t[0], t[1], t[2], ray, pl);
+  return intersect_triangle_data<PROGRAM>(t[0], t[1], t[2], ray, pl, fastRcp);
 }
 template <int PROGRAM>
-__device__ __forceinline__ bool intersect_triangle_lds(uint32_t ldsTris, int prim, const Ray& ray, Hit& pl) {
+__device__ __forceinline__ bool intersect_triangle_lds(uint32_t ldsTris, int prim, const Ray& ray, Hit& pl, bool fastRcp = false) {
   const LdsF4 t = (LdsF4)(size_t)(ldsTris + 48u * (uint32_t)prim);
-  return intersect_triangle_data<PROGRAM>(ld_lds(t), ld_lds(t + 1), ld_lds(t + 2), ray, pl);
+  return intersect_triangle_data<PROGRAM>(ld_lds(t), ld_lds(t + 1), ld_lds(t + 2), ray, pl, fastRcp);
 }
 
 // The same test for the packet walks, where the triangle sits in SGPRs and the whole wave runs it anyway: no per-lane early
@@ -228,7 +262,7 @@ __device__ __forceinline__ bool intersect_triangle_lds(uint32_t ldsTris, int pri
 // whatever their registers hold and are masked out of every decision (no float exception traps on this path).
 template <int PROGRAM>
 __device__ __forceinline__ bool intersect_triangle_packet(const float4 t0, const float4 t1, const float4 t2, const Ray& ray, Hit& pl,
-                                                          bool active, int prim) {
+                                                          bool active, int prim, bool fastRcp = false) {
   const V4 A = mk4(t0.x, t0.y, t0.z, 1.0f);
   const V4 v0v1 = mk4(t0.w, t1.x, t1.y, 0.0f);
   const V4 v0v2 = mk4(t1.z, t1.w, t2.x, 0.0f);
@@ -237,7 +271,7 @@ __device__ __forceinline__ bool intersect_triangle_packet(const float4 t0, const
   const float eps = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
                     : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
   bool ok = active && !(__builtin_fabsf(det) < eps);
-  const float invDet = 1.0f / det;
+  const float invDet = fastRcp ? Math<2>::rcp(det) : 1.0f / det;
   const V4 tvec = sub4(ray.o, A);
   const float u = dot4(tvec, pvec) * invDet;
   ok = ok && !(u < 0.0f || u > 1.0f);
@@ -260,7 +294,7 @@ __device__ __forceinline__ bool intersect_triangle_packet(const float4 t0, const
 // payload needs to be carried or updated at all.
 template <int PROGRAM>
 __device__ __forceinline__ bool intersect_triangle_anyhit(const float4 t0, const float4 t1, const float4 t2, const Ray& ray, float tmax,
-                                                          bool active) {
+                                                          bool active, bool fastRcp = false) {
   const V4 A = mk4(t0.x, t0.y, t0.z, 1.0f);
   const V4 v0v1 = mk4(t0.w, t1.x, t1.y, 0.0f);
   const V4 v0v2 = mk4(t1.z, t1.w, t2.x, 0.0f);
@@ -269,7 +303,7 @@ __device__ __forceinline__ bool intersect_triangle_anyhit(const float4 t0, const
   const float eps = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
                     : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
   bool ok = active && !(__builtin_fabsf(det) < eps);
-  const float invDet = 1.0f / det;
+  const float invDet = fastRcp ? Math<2>::rcp(det) : 1.0f / det;
   const V4 tvec = sub4(ray.o, A);
   const float u = dot4(tvec, pvec) * invDet;
   ok = ok && !(u < 0.0f || u > 1.0f);
@@ -434,7 +468,7 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
     if (pend >= 0) {   // the leaf noted in the previous iteration
       LT_WAVE_COUNT(wTri);
       if (STATS) c.tris += pendCount;    // the reference *calls* intersectTriangle primitiveCount times
-      if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl) : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl)) {
+      if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl, sc.fastRcp != 0u) : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, sc.fastRcp != 0u)) {
         pl.prim = pend;
         pl.hitType = 1;
         if (ANYHIT) return;
@@ -458,7 +492,7 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
   if (pend >= 0) {
     LT_WAVE_COUNT(wTri);
     if (STATS) c.tris += pendCount;
-    if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl) : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl)) {
+    if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl, sc.fastRcp != 0u) : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, sc.fastRcp != 0u)) {
       pl.prim = pend;
       pl.hitType = 1;
     }
@@ -466,11 +500,11 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
 }
 
 // Compile-time configuration of one kernel instantiation.
-template <bool DEEP_, bool STATS_, bool DEVLIBM_, bool LDSSCENE_ = false>
+template <bool DEEP_, bool STATS_, int DEVLIBM_, bool LDSSCENE_ = false>
 struct Config {
   static constexpr bool kDeep = DEEP_;       // BVH deeper than the LDS stack: spill entries >= kLdsStack to scratch
   static constexpr bool kStats = STATS_;     // count rays / node visits / triangle tests
-  static constexpr bool kDevLibm = DEVLIBM_; // device-library leaf math (Math<true>)
+  static constexpr int kDevLibm = DEVLIBM_;  // math flavour: 0 portable, 1 device-library leaf math, 2 as shipped (Math<>)
   static constexpr bool kLdsScene = LDSSCENE_; // the per-lane walks read nodes and triangles from the workgroup's LDS copy (SceneDev::ldsNodes)
 };
 
@@ -547,7 +581,7 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
         if (STATS) c.tris += count;    // the reference *calls* intersectTriangle primitiveCount times
         const ConstF4 t = tris + 3 * (size_t)(uint32_t)off;
         const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
-        if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl)) {
+        if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl, sc.fastRcp != 0u)) {
           pl.prim = off;
           pl.hitType = 1;
         }
@@ -581,10 +615,10 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
     const ConstF4 t = tris + 3 * (size_t)off;
     const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
 #ifndef LT_BRANCHY_PACKET_LEAF
-    intersect_triangle_packet<PROGRAM>(t0, t1, t2, ray, pl, ((m >> lane) & 1ull) != 0ull, (int)off);
+    intersect_triangle_packet<PROGRAM>(t0, t1, t2, ray, pl, ((m >> lane) & 1ull) != 0ull, (int)off, sc.fastRcp != 0u);
 #else
     if ((m >> lane) & 1ull) {
-      if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl)) {
+      if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl, sc.fastRcp != 0u)) {
         pl.prim = (int)off;
         pl.hitType = 1;
       }
@@ -608,7 +642,7 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
                       : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
     const uint32_t ldsBase = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)ldsWave;
     packet_closest_walk<NEG>((const void*)sc.pairs, (const void*)sc.tris, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y, ray.d.z,
-                             ray.d.w, eps, ldsBase, cur, mask, pl.t, pl.u, pl.v, pl.prim, pl.hitType);
+                             ray.d.w, eps, sc.fastRcp, ldsBase, cur, mask, pl.t, pl.u, pl.v, pl.prim, pl.hitType);
     return;
   }
 #endif
@@ -697,7 +731,7 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
     const ConstF4 t = tris + 3 * (size_t)off;
     const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
     const bool active = (((m & openMask) >> lane) & 1ull) != 0ull && (int)off != ign;
-    openMask &= ~__builtin_amdgcn_ballot_w64(intersect_triangle_anyhit<PROGRAM>(t0, t1, t2, ray, tmax, active));
+    openMask &= ~__builtin_amdgcn_ballot_w64(intersect_triangle_anyhit<PROGRAM>(t0, t1, t2, ray, tmax, active, sc.fastRcp != 0u));
   };
   auto walk = [&]() {
     u64 mask;
@@ -716,7 +750,7 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
                             : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
       const uint32_t ldsBase = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)ldsWave;
       openMask = packet_anyhit_walk<NEG>((const void*)sc.pairs, (const void*)sc.tris, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y,
-                                         ray.d.z, ray.d.w, tmax, ign, epsBits, ldsBase, mask, openMask);
+                                         ray.d.z, ray.d.w, tmax, ign, epsBits, sc.fastRcp, ldsBase, mask, openMask);
       return;
     }
 #endif
@@ -853,7 +887,11 @@ __device__ __forceinline__ V3 barycentrics(float u, float v) {   // (float3)(1.0
   return V3{(float)((1.0 - (double)u) - (double)v), u, v};
 }
 // float3 A*w.x + B*w.y + C*w.z evaluated (A*wx + B*wy) + C*wz (acc.cl:247)
+template <int M = 0>
 __device__ __forceinline__ V3 bary3(const float* a, const float* b, const float* cc, V3 w) {
+  if (Math<M>::kShipped)   // fma(C, w.z, fma(A, w.x, B * w.y))
+    return V3{__builtin_fmaf(cc[0], w.z, __builtin_fmaf(a[0], w.x, b[0] * w.y)), __builtin_fmaf(cc[1], w.z, __builtin_fmaf(a[1], w.x, b[1] * w.y)),
+              __builtin_fmaf(cc[2], w.z, __builtin_fmaf(a[2], w.x, b[2] * w.y))};
   return V3{(a[0] * w.x + b[0] * w.y) + cc[0] * w.z, (a[1] * w.x + b[1] * w.y) + cc[1] * w.z,
             (a[2] * w.x + b[2] * w.y) + cc[2] * w.z};
 }
@@ -884,22 +922,22 @@ __device__ inline bool direct_light(const SceneDev& sc, const float* pr, int pri
   // i.e. three double-precision sin / fmod evaluations that want every register -- and only then the hit primitive's own
   // positions and normals, fenced so that the compiler does not issue those loads ahead of the randoms and carry 19 floats
   // through them in scratch memory.
-  const float* lp = light_prim(sc, random_(fx, fy, seedIndex));
-  float uvx = random_(fx, fy, seedU);
-  float uvy = random_(fx, fy, seedV);
+  const float* lp = light_prim(sc, random_<CFG::kDevLibm>(fx, fy, seedIndex));
+  float uvx = random_<CFG::kDevLibm>(fx, fy, seedU);
+  float uvy = random_<CFG::kDevLibm>(fx, fy, seedV);
   if (uvx + uvy > 1.0f) {
     uvx = 1.0f - uvx;
     uvy = 1.0f - uvy;
   }
   const V3 lb = barycentrics(uvx, uvy);
-  const V3 l3 = bary3(lp + 0, lp + 3, lp + 6, lb);
+  const V3 l3 = bary3<CFG::kDevLibm>(lp + 0, lp + 3, lp + 6, lb);
   const V4 lightPosition = mk4(l3.x, l3.y, l3.z, 1.0f);
   asm volatile("" ::: "memory");
 
   const V3 b = barycentrics(u, v);
-  const V3 p3 = bary3(pr + 0, pr + 3, pr + 6, b);
+  const V3 p3 = bary3<CFG::kDevLibm>(pr + 0, pr + 3, pr + 6, b);
   position = mk4(p3.x, p3.y, p3.z, 1.0f);
-  const V3 n3 = bary3(pr + 9, pr + 12, pr + 15, b);
+  const V3 n3 = bary3<CFG::kDevLibm>(pr + 9, pr + 12, pr + 15, b);
   normal = mk4(n3.x, n3.y, n3.z, normal_w);
 
   const V4 toLight = normalize4<CFG::kDevLibm>(sub4(lightPosition, position));
@@ -916,11 +954,16 @@ __device__ inline bool direct_light(const SceneDev& sc, const float* pr, int pri
 }
 
 // basic.cl:65-71
+template <int M = 0>
 __device__ inline V4 refract_(V4 I, V4 N, float firstIOR, float secondIOR) {
-  const float n = firstIOR / secondIOR;
+  const float n = secondIOR == 1.0f ? firstIOR : Math<M>::fdiv(firstIOR, secondIOR);   // (x / 1.0f folds to x at compile time in the reference)
   const float cosI = -dot4(N, I);
   const float sinT2 = (float)((double)(n * n) * (1.0 - (double)(cosI * cosI)));
   const float cosT = (float)sqrt(1.0 - (double)sinT2);
+  if (Math<M>::kShipped) {   // n * I + (n * cosI - cosT) * N, contracted: fma(n, I, fma(n, cosI, -cosT) * N)
+    const float k = __builtin_fmaf(n, cosI, -cosT);
+    return mk4(__builtin_fmaf(n, I.x, k * N.x), __builtin_fmaf(n, I.y, k * N.y), __builtin_fmaf(n, I.z, k * N.z), __builtin_fmaf(n, I.w, k * N.w));
+  }
   return add4(scale4(n, I), scale4(n * cosI - cosT, N));
 }
 
@@ -930,11 +973,11 @@ __device__ inline void trace_ray_through_lens(const SceneDev& sc, Hit& pl, Ray& 
   const float* pr = prim_ptr(sc, pl.prim);
   const Material* m = sc.mats + prim_material(pr);
   V3 b = barycentrics(pl.u, pl.v);
-  V3 p3 = bary3(pr + 0, pr + 3, pr + 6, b);
+  V3 p3 = bary3<CFG::kDevLibm>(pr + 0, pr + 3, pr + 6, b);
   V4 position = mk4(p3.x, p3.y, p3.z, 1.0f);
-  V3 n3 = bary3(pr + 9, pr + 12, pr + 15, b);
+  V3 n3 = bary3<CFG::kDevLibm>(pr + 9, pr + 12, pr + 15, b);
   V4 normal = mk4(n3.x, n3.y, n3.z, 0.0f);
-  V4 tdir = refract_(ray.d, normal, 1.0f, m->ior);
+  V4 tdir = refract_<CFG::kDevLibm>(ray.d, normal, 1.0f, m->ior);
 
   Hit pl2{0, 0, kFltMax, 0.0f, 0.0f};
   const Ray ray2{position, tdir};
@@ -943,11 +986,11 @@ __device__ inline void trace_ray_through_lens(const SceneDev& sc, Hit& pl, Ray& 
   pr = prim_ptr(sc, pl2.prim);
   m = sc.mats + prim_material(pr);
   b = barycentrics(pl2.u, pl2.v);
-  p3 = bary3(pr + 0, pr + 3, pr + 6, b);
+  p3 = bary3<CFG::kDevLibm>(pr + 0, pr + 3, pr + 6, b);
   position = mk4(p3.x, p3.y, p3.z, 1.0f);
-  n3 = bary3(pr + 9, pr + 12, pr + 15, b);
+  n3 = bary3<CFG::kDevLibm>(pr + 9, pr + 12, pr + 15, b);
   normal = mk4(n3.x, n3.y, n3.z, 0.0f);
-  tdir = refract_(tdir, neg4(normal), m->ior, 1.0f);
+  tdir = refract_<CFG::kDevLibm>(tdir, neg4(normal), m->ior, 1.0f);
 
   pl = Hit{0, 0, kFltMax, 0.0f, 0.0f};
   ray.o = position;
@@ -1010,18 +1053,21 @@ __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, fl
 }
 
 // gi.cl:68-74
-template <bool DEVLIBM>
+template <int DEVLIBM>
 __device__ inline V4 uniform_sample_hemisphere(float uvx, float uvy) {
   const float z = uvx;
-  const float r = __builtin_sqrtf(__builtin_fmaxf(0.0f, 1.0f - z * z));
+  const float r = Math<DEVLIBM>::sqrt_user(__builtin_fmaxf(0.0f, Math<DEVLIBM>::kShipped ? __builtin_fmaf(-z, z, 1.0f) : 1.0f - z * z));
   const float phi = (float)(2.0 * M_PI * (double)uvy);
   return mk4(r * Math<DEVLIBM>::cos(phi), z, r * Math<DEVLIBM>::sin(phi), 0.0f);
 }
 // gi.cl:76-81
-template <bool DEVLIBM>
+template <int DEVLIBM>
 __device__ inline V4 align_hemisphere(V4 h, V4 up) {
   const V4 right = normalize4<DEVLIBM>(cross4(up, mk4(0.0072f, 1.0f, 0.0034f, 0.0f)));
   const V4 forward = cross4(right, up);
+  if (Math<DEVLIBM>::kShipped)   // fma(h.z, forward, fma(h.x, right, h.y * up))
+    return mk4(__builtin_fmaf(h.z, forward.x, __builtin_fmaf(h.x, right.x, h.y * up.x)), __builtin_fmaf(h.z, forward.y, __builtin_fmaf(h.x, right.y, h.y * up.y)),
+               __builtin_fmaf(h.z, forward.z, __builtin_fmaf(h.x, right.z, h.y * up.z)), __builtin_fmaf(h.z, forward.w, __builtin_fmaf(h.x, right.w, h.y * up.w)));
   return add4(add4(scale4(h.x, right), scale4(h.y, up)), scale4(h.z, forward));
 }
 
@@ -1043,7 +1089,7 @@ __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx
                                        position, normal, ndotl, st, c)) {
       direct = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
     }
-    V4 hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_(fx, fy, (float)(s + 3u)), random_(fx, fy, (float)(s + 4u)));
+    V4 hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_<CFG::kDevLibm>(fx, fy, (float)(s + 3u)), random_<CFG::kDevLibm>(fx, fy, (float)(s + 4u)));
     Ray ext{position, align_hemisphere<CFG::kDevLibm>(hemi, normal)};
     V4 previousNormal = normal;
     int previousPrimitive = pl.prim;
@@ -1056,9 +1102,9 @@ __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx
       if (is_light(sc.lights, epl.prim)) {
         // hit a light: add and keep looping with the SAME ray (gi.cl:319-321)
         const float k = dot4(previousNormal, ext.d);
-        indirect.x += (w * 1.0f) * k;
-        indirect.y += (w * 1.0f) * k;
-        indirect.z += (w * 1.0f) * k;
+        indirect.x = Math<CFG::kDevLibm>::mad(w * 1.0f, k, indirect.x);
+        indirect.y = Math<CFG::kDevLibm>::mad(w * 1.0f, k, indirect.y);
+        indirect.z = Math<CFG::kDevLibm>::mad(w * 1.0f, k, indirect.z);
       } else if (epl.hitType == 1) {
         const float* epr = prim_ptr(sc, epl.prim);
         const Material* em = sc.mats + prim_material(epr);
@@ -1066,10 +1112,10 @@ __device__ inline V3 shade_gi(const SceneDev& sc, const Ray& cameraRay, float fx
         float endotl;
         if (direct_light<kGI, CFG>(sc, epr, epl.prim, epl.u, epl.v, fx, fy, (float)(sd + 5u), (float)(sd + 6u),
                                            (float)(sd + 7u), 1.0f, epos, enorm, endotl, st, c)) {
-          indirect.x += (w * em->diffuse[0]) * endotl;
-          indirect.y += (w * em->diffuse[1]) * endotl;
-          indirect.z += (w * em->diffuse[2]) * endotl;
-          hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_(fx, fy, (float)(sd + 8u)), random_(fx, fy, (float)(sd + 9u)));
+          indirect.x = Math<CFG::kDevLibm>::mad(w * em->diffuse[0], endotl, indirect.x);
+          indirect.y = Math<CFG::kDevLibm>::mad(w * em->diffuse[1], endotl, indirect.y);
+          indirect.z = Math<CFG::kDevLibm>::mad(w * em->diffuse[2], endotl, indirect.z);
+          hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_<CFG::kDevLibm>(fx, fy, (float)(sd + 8u)), random_<CFG::kDevLibm>(fx, fy, (float)(sd + 9u)));
           ext.o = epos;
           ext.d = align_hemisphere<CFG::kDevLibm>(hemi, enorm);
           previousNormal = enorm;
@@ -1118,15 +1164,15 @@ struct FrameParams {
 };
 
 // Camera ray of pixel (x,y): acc.cl:304-312.
-template <bool DEVLIBM>
+template <int DEVLIBM>
 __device__ __forceinline__ Ray camera_ray(const FrameParams& fp, int x, int y, float& fx, float& fy) {
   const V4 cameraPosition = mk4(fp.camx, fp.camy, fp.camz, 1.0f);
-  const V4 film = mk4(((float)x / (float)fp.width) - 0.5f, ((float)y / (float)fp.height) - 0.5f, 0.0f, 1.0f);
+  const V4 film = mk4(Math<DEVLIBM>::fdiv((float)x, (float)fp.width) - 0.5f, Math<DEVLIBM>::fdiv((float)y, (float)fp.height) - 0.5f, 0.0f, 1.0f);
   const V4 aperture = mk4(fp.apx, fp.apy, fp.apz, 1.0f);
   Ray ray{add4(cameraPosition, film), sub4(aperture, film)};
   const float cy = DEVLIBM ? ::cosf(fp.yaw) : fp.cosYaw, sy = DEVLIBM ? ::sinf(fp.yaw) : fp.sinYaw;
-  const float newX = (cy * ray.d.x) + (sy * ray.d.z);
-  const float newZ = (-sy * ray.d.x) + (cy * ray.d.z);
+  const float newX = Math<DEVLIBM>::mad(cy, ray.d.x, sy * ray.d.z);
+  const float newZ = Math<DEVLIBM>::mad(-sy, ray.d.x, cy * ray.d.z);
   ray.d.x = newX;
   ray.d.z = newZ;
   fx = film.x;
@@ -1173,9 +1219,9 @@ __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, uint
       if (k == 0) {
         color = cn;
       } else {
-        const float a = ((float)(25 - k)) / (float)25;
-        color = V3{((1.0f - a) * color.x) + (a * cn.x), ((1.0f - a) * color.y) + (a * cn.y),
-                   ((1.0f - a) * color.z) + (a * cn.z)};
+        const float a = Math<CFG::kDevLibm>::div25((float)(25 - k));
+        color = V3{Math<CFG::kDevLibm>::mad(1.0f - a, color.x, a * cn.x), Math<CFG::kDevLibm>::mad(1.0f - a, color.y, a * cn.y),
+                   Math<CFG::kDevLibm>::mad(1.0f - a, color.z, a * cn.z)};
       }
     }
   }

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_primary_kerne
                                           normal, ndotl, st, c)) {
           direct = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
         }
-        const V4 hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_(fx, fy, (float)(s + 3u)), random_(fx, fy, (float)(s + 4u)));
+        const V4 hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_<CFG::kDevLibm>(fx, fy, (float)(s + 3u)), random_<CFG::kDevLibm>(fx, fy, (float)(s + 4u)));
         dir = align_hemisphere<CFG::kDevLibm>(hemi, normal);
         prim = pl.prim;
         alive = fp.giMaxDepth > 0;
@@ -317,9 +317,9 @@ void lt_gi_bounce_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t dept
         const float k = dot4(previousNormal, ext.d);
         for (int dd2 = d; dd2 < fp.giMaxDepth; dd2++) {
           const float w = (float)(1.0 / (double)(dd2 + 1));
-          ind.x += (w * 1.0f) * k;
-          ind.y += (w * 1.0f) * k;
-          ind.z += (w * 1.0f) * k;
+          ind.x = Math<CFG::kDevLibm>::mad(w * 1.0f, k, ind.x);
+          ind.y = Math<CFG::kDevLibm>::mad(w * 1.0f, k, ind.y);
+          ind.z = Math<CFG::kDevLibm>::mad(w * 1.0f, k, ind.z);
         }
         gp.indirect[pix] = ind;
       } else if (epl.hitType == 1) {
@@ -329,11 +329,11 @@ void lt_gi_bounce_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t dept
         float endotl;
         if (direct_light<kGI, CFG>(sc, epr, epl.prim, epl.u, epl.v, fx, fy, (float)(sd + 5u), (float)(sd + 6u), (float)(sd + 7u), 1.0f,
                                    epos, enorm, endotl, st, c)) {
-          ind.x += (w * em->diffuse[0]) * endotl;
-          ind.y += (w * em->diffuse[1]) * endotl;
-          ind.z += (w * em->diffuse[2]) * endotl;
+          ind.x = Math<CFG::kDevLibm>::mad(w * em->diffuse[0], endotl, ind.x);
+          ind.y = Math<CFG::kDevLibm>::mad(w * em->diffuse[1], endotl, ind.y);
+          ind.z = Math<CFG::kDevLibm>::mad(w * em->diffuse[2], endotl, ind.z);
           gp.indirect[pix] = ind;
-          const V4 hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_(fx, fy, (float)(sd + 8u)), random_(fx, fy, (float)(sd + 9u)));
+          const V4 hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_<CFG::kDevLibm>(fx, fy, (float)(sd + 8u)), random_<CFG::kDevLibm>(fx, fy, (float)(sd + 9u)));
           ndir = align_hemisphere<CFG::kDevLibm>(hemi, enorm);
           hitPrim = epl.prim;
           alive = d + 1 < fp.giMaxDepth;
@@ -398,8 +398,9 @@ __global__ void lt_gi_blend25_kernel(FrameParams fp, GiParams gp, const float* _
     if (kk == 0u) {
       color = cn;
     } else {
-      const float a = ((float)(25 - (int)kk)) / (float)25;
-      color = V3{((1.0f - a) * color.x) + (a * cn.x), ((1.0f - a) * color.y) + (a * cn.y), ((1.0f - a) * color.z) + (a * cn.z)};
+      const float a = Math<CFG::kDevLibm>::div25((float)(25 - (int)kk));
+      color = V3{Math<CFG::kDevLibm>::mad(1.0f - a, color.x, a * cn.x), Math<CFG::kDevLibm>::mad(1.0f - a, color.y, a * cn.y),
+                 Math<CFG::kDevLibm>::mad(1.0f - a, color.z, a * cn.z)};
     }
   }
   if (k0 + n < 25u) {

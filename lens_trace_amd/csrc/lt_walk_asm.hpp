@@ -18,7 +18,8 @@
 //   * branches test SCC straight from the mask arithmetic; the wave-uniform stack (child reference + 64-bit lane mask per
 //     entry, one row of the wave's LDS stack each) is written / read with three ds_*_b32 of identical data per lane;
 //   * the triangle test (acc.cl:72-111 on the re-tiled 48-byte triangle: cross = fma(a, b, -(c * d)), dot = fma chain + the
-//     `w` terms, IEEE 1 / det by the div_scale / rcp / fma / div_fmas / div_fixup sequence hipcc emits for `1.0f / x`, each
+//     `w` terms, IEEE 1 / det by the div_scale / rcp / fma / div_fmas / div_fixup sequence hipcc emits for `1.0f / x` -- or,
+//     for the as-shipped math flavour (operand `fast`), the 2.5-ulp form the reference's NULL build options give it -- each
 //     reject written as the reference's negated compare) runs with EXEC = the lanes that reached the leaf, and every test
 //     NARROWS EXEC (v_cmpx): what is left of EXEC at the end is the mask of lanes that accept the hit;
 //
@@ -167,6 +168,8 @@ typedef unsigned long long lt_u64;
   "v_fmac_f32_e32 %[t0], " LT_R_E1Y ", %[t5]\n"                                                                                 \
   "v_fmac_f32_e32 %[t0], " LT_R_E1Z ", %[t6]\n"                                                                                 \
   "v_add_f32_e32 %[t0], 0, %[t0]\n"                 /* det */                                                                   \
+  "s_cmp_lg_u32 %[fast], 0\n"                                                                                                   \
+  "s_cbranch_scc1 .LfastRcp%=\n"                                                                                                \
   "v_div_scale_f32 %[t1], " LT_R_HML ", %[t0], %[t0], 1.0\n"                                                                    \
   "v_rcp_f32_e32 %[t2], %[t1]\n"                                                                                                \
   "v_cmpx_nlt_f32_e64 " LT_R_HML ", |%[t0]|, %[eps]\n" /* !(fabs(det) < epsilon) */                                             \
@@ -180,7 +183,18 @@ typedef unsigned long long lt_u64;
   "v_fmac_f32_e32 %[t9], %[t10], %[t2]\n"                                                                                       \
   "v_fma_f32 %[t1], -%[t1], %[t9], %[t3]\n"                                                                                     \
   "v_div_fmas_f32 %[t1], %[t1], %[t2], %[t9]\n"                                                                                 \
-  "v_div_fixup_f32 %[t0], %[t1], %[t0], 1.0\n"      /* invDet = 1 / det */                                                      \
+  "v_div_fixup_f32 %[t0], %[t1], %[t0], 1.0\n"      /* invDet = 1 / det, correctly rounded */                                   \
+  "s_branch .LrcpDone%=\n"                                                                                                      \
+  ".LfastRcp%=:\n"                                  /* the as-shipped build's 1 / det: ldexp(rcp(frexp_mant), -frexp_exp) */    \
+  "v_frexp_mant_f32_e32 %[t1], %[t0]\n"                                                                                         \
+  "v_rcp_f32_e32 %[t1], %[t1]\n"                                                                                                \
+  "v_cmpx_nlt_f32_e64 " LT_R_HML ", |%[t0]|, %[eps]\n"                                                                          \
+  "v_subrev_f32_e32 %[t7], " LT_R_AX ", %[ox]\n"                                                                                \
+  "v_subrev_f32_e32 %[t8], " LT_R_AY ", %[oy]\n"                                                                                \
+  "v_frexp_exp_i32_f32_e32 %[t2], %[t0]\n"                                                                                      \
+  "v_sub_u32_e32 %[t2], 0, %[t2]\n"                                                                                             \
+  "v_ldexp_f32 %[t0], %[t1], %[t2]\n"                                                                                           \
+  ".LrcpDone%=:\n"                                                                                                              \
   "v_subrev_f32_e32 %[t9], " LT_R_AZ ", %[oz]\n"                                                                                \
   "v_mul_f32_e32 %[t1], %[t7], %[t4]\n"                                                                                         \
   "v_fmac_f32_e32 %[t1], %[t8], %[t5]\n"                                                                                        \
@@ -309,7 +323,7 @@ typedef unsigned long long lt_u64;
 template <int NEG>
 __device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, const void* tris, float ox, float oy, float oz, float ix, float iy,
                                                      float iz, float dx, float dy, float dz, float dw, float tmax, int ign, float eps,
-                                                     uint32_t lds, lt_u64 mask, lt_u64 open) {
+                                                     uint32_t fast, uint32_t lds, lt_u64 mask, lt_u64 open) {
   uint32_t cur = 0u, sp = 0u;
   float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
 #define LT_ANYHIT_INSTANCE(BOXES)                                                                                                        \
@@ -318,7 +332,7 @@ __device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, const vo
                  [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9),         \
                  [t10] "=&v"(t10)                                                                                                        \
                : [pairs] "s"(pairs), [tris] "s"(tris), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), \
-                 [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [dw] "v"(dw), [tmax] "v"(tmax), [ign] "v"(ign), [eps] "s"(eps), [lds] "v"(lds) \
+                 [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [dw] "v"(dw), [tmax] "v"(tmax), [ign] "v"(ign), [eps] "s"(eps), [fast] "s"(fast), [lds] "v"(lds) \
                : LT_ASM_CLOBBERS)
   if constexpr (NEG == 0) LT_ANYHIT_INSTANCE(LT_ASM_BOXES_0);
   else if constexpr (NEG == 1) LT_ANYHIT_INSTANCE(LT_ASM_BOXES_1);
@@ -421,8 +435,8 @@ __device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, const vo
 // that hit the root's box.
 template <int NEG>
 __device__ __forceinline__ void packet_closest_walk(const void* pairs, const void* tris, float ox, float oy, float oz, float ix, float iy,
-                                                    float iz, float dx, float dy, float dz, float dw, float eps, uint32_t lds, uint32_t cur,
-                                                    lt_u64 mask, float& pt, float& pu, float& pv, int& pprim, int& phit) {
+                                                    float iz, float dx, float dy, float dz, float dw, float eps, uint32_t fast, uint32_t lds,
+                                                    uint32_t cur, lt_u64 mask, float& pt, float& pu, float& pv, int& pprim, int& phit) {
   uint32_t sp = 0u;
   float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
 #define LT_CLOSEST_INSTANCE(BOXES, NEGBITS)                                                                                              \
@@ -431,7 +445,7 @@ __device__ __forceinline__ void packet_closest_walk(const void* pairs, const voi
                  [phit] "+v"(phit), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),     \
                  [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9), [t10] "=&v"(t10)                                        \
                : [pairs] "s"(pairs), [tris] "s"(tris), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), \
-                 [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [dw] "v"(dw), [eps] "s"(eps), [lds] "v"(lds)                                  \
+                 [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [dw] "v"(dw), [eps] "s"(eps), [fast] "s"(fast), [lds] "v"(lds)                  \
                : LT_ASM_CLOBBERS)
   if constexpr (NEG == 0) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_0, "0");
   else if constexpr (NEG == 1) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_1, "1");

@@ -150,6 +150,34 @@ def test_report_against_default_build_options(renderer, scene, kernel, mode, W, 
         assert poff <= 4 * (2 + W * H // (100 if kernel in ("basic_lighting", "global_illumination25") else 1000))
 
 
+SHIPPED_CASES = DEFAULT_CASES + [
+    ("cornell_box_O0", "basic", 1, 128, 128, 0, 0.0),
+    ("cornell_box_lens_O0", "custom_opencl", 0, 128, 128, 0, 0.0),
+    ("cornell_box_O0", "accumulator", 0, 96, 64, 3, 0.02),          # yaw != 0: the fused rotation
+    ("cornell_box_O0", "global_illumination", 0, 96, 64, 1, -0.015),
+    ("cornell_box_O0", "basic_lighting", 1, 64, 64, 0, 0.01),
+]
+SHIPPED_CASES = [c if len(c) == 7 else c + (0.0,) for c in SHIPPED_CASES]
+
+
+@pytest.mark.parametrize("scene,kernel,mode,W,H,frame,yaw", SHIPPED_CASES)
+def test_as_shipped_flavour_matches_reference_default_build(renderer, monkeypatch, scene, kernel, mode, W, H, frame, yaw):
+    """LT_RENDER_FLAG_AS_SHIPPED_MATH (asShippedMath) against the reference's kernels built the way RendererOpenCL builds them --
+    clBuildProgram with NULL options (src/opencl/renderer_opencl.cpp:50): contraction of a*b+c inside expressions, 2.5-ulp
+    divide, 3-ulp sqrt -- all six programs, both kernel modes, both GI execution paths: BIT-IDENTICAL."""
+    if "global_illumination" in kernel:
+        monkeypatch.setenv("LT_GI_MEGAKERNEL", "0" if frame % 2 else "1")
+    s = sc.load_ltsb(os.path.join(GOLDEN, scene + ".ltsb")).validate()
+    cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, frame)
+    ref = ref_gpu.render(s, cam, W, H, kernel, "default", mode)
+    got = hip(renderer, s, kernel, W, H, cam, mode, asShippedMath=True)
+    nbits = int((got != ref).sum())
+    print("REF-as-shipped %s/%s m%d %dx%d f%d yaw %g: rms=%.3g floats_differing=%d/%d pixels_off_by_1e-4=%d" % (
+        scene, kernel, mode, W, H, frame, yaw, rms(got, ref), nbits, ref.size, pixels_off(got, ref)))
+    assert ref.sum() > 0
+    assert nbits == 0
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The machinery the benchmark times, against the reference's accumulator.cl on big synthetic scenes.
 _synth = {}
