@@ -25,11 +25,10 @@ launch / launch time -- several times the HBM peak, which is what "on_chip_reuse
 `cpu_baseline` is the CPU oracle (a C restatement of the reference kernels, kind "port") on this host's cores over
 one bounded sample of the same workload; it is a reported baseline, not a target.
 
-Math flavour: the library's default -- bit-identical to the reference's OpenCL kernels compiled for gfx950 with
--ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt ("strict"; tests/test_gpu_reference_kernels.py,
-tests/test_gpu_full_size.py compare the whole 4K frame).  The reference itself passes NULL build options
-(src/opencl/renderer_opencl.cpp:50), under which the OpenCL compiler may contract a*b+c as it sees fit; against that build
-the stochastic programs differ in a few pixels per image (reported by the same test file)."""
+Math flavour: the library's default -- bit-identical to the reference's OpenCL kernels compiled for gfx950 the way the reference
+compiles them, clBuildProgram with NULL options (src/opencl/renderer_opencl.cpp:50: a*b+c contracted inside expressions, 2.5-ulp
+divide, 3-ulp sqrt).  tests/test_gpu_full_size.py compares the whole 4K frame of this workload, tests/test_gpu_reference_kernels.py
+all six programs."""
 import argparse
 import json
 import os
@@ -277,9 +276,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "note": "math flavour = the library default, bit-identical to the reference's OpenCL kernels built for gfx950 with "
-                    "-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt (the reference passes NULL options, under which the "
-                    "stochastic programs differ from this build in a few pixels per image: tests/test_gpu_reference_kernels.py); "
+            "note": "math flavour = the library default, bit-identical to the reference's OpenCL kernels built for gfx950 as the "
+                    "reference builds them (NULL build options, renderer_opencl.cpp:50) -- whole 4K frame of this workload in "
+                    "tests/test_gpu_full_size.py; "
                     "shadow rays stop at the first accepted hit (their callers read only hitType): same pixels, fewer node visits "
                     "than the reference algorithm, whose counts (measured once with the counting kernel) price roofline.algorithmic_gbs",
             "config": {"workload": "%s, %d triangles, %dx%d, %d spp running mean, program %s, %s" % (

@@ -30,14 +30,12 @@ struct ProgressivePropertiesHIP {
 struct BackendPropertiesHIP {
   StructureType sType;          // STRUCTURE_TYPE_BACKEND_PROPERTIES_HIP
   void* pNext;
-  // 0 (default): rsqrt / sqrt / sinf / cosf / clamp as ROCm's OpenCL device library gives them to the reference kernels on
-  // this GPU -- render() is bit-identical to RendererOpenCL running the same kernel file on the MI355X.  1: the correctly
-  // rounded forms every IEEE machine reproduces (what the CPU oracle computes; LT_RENDER_FLAG_PORTABLE_MATH).
+  // Floating-point flavour (include/lenstrace_hip.h, LT_RENDER_FLAG_*_MATH).  Both 0 (default): render() is bit-identical to
+  // RendererOpenCL running the same kernel file on the MI355X (clBuildProgram with NULL options, as the reference builds it).
+  // strictMath: the same kernels built with -ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt.  portableMath: strict,
+  // with the device library's approximate leaf functions in correctly rounded forms (what the CPU oracle computes).
   uint32_t portableMath;
-  // 1: the reference kernels as RendererOpenCL builds them -- clBuildProgram with NULL options: `a*b + c` of one source
-  // expression fused, float divide / sqrt at the OpenCL default accuracy -- bit for bit on this GPU (LT_RENDER_FLAG_AS_SHIPPED_MATH;
-  // excludes portableMath)
-  uint32_t asShippedMath;
+  uint32_t strictMath;
   // Scene-change contract.  0 (default): every render() hashes the four scene buffers in full and re-uploads when anything
   // changed -- the reference's "upload on every call" semantics (renderer_opencl.cpp:107-120) at the price of one pass over
   // host memory (~20 ms for the 1 M-triangle scene).  != 0: the caller versions its scene -- the buffers are re-examined only

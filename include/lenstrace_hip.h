@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define LT_HIP_ABI_VERSION 3
+#define LT_HIP_ABI_VERSION 4
 
 typedef struct lt_hip_context lt_hip_context;
 
@@ -81,22 +81,22 @@ enum {
   LT_RENDER_FLAG_STATS = 1u,    /* count rays / node visits / triangle tests with device atomics (slower) */
   LT_RENDER_FLAG_PIXEL_COUNTERS = 2u,/* diagnostic (implies STATS, needs depth >= 4): instead of the colour, write each
                                         pixel's own {rays, shadow rays, node visits, triangle tests} as 4 floats */
-  LT_RENDER_FLAG_DEVICE_LIBM = 4u,   /* accepted and ignored since ABI 3: it names what is now the default flavour (below) */
-  LT_RENDER_FLAG_PORTABLE_MATH = 8u  /* Floating-point flavour of four leaf functions ("Floating-point model").
-                                        DEFAULT (flag clear): rsqrt / sqrt / sinf / cosf / clamp exactly as ROCm's OpenCL device
-                                        library gives them to the reference kernels on this GPU (v_rsq_f32, v_sqrt_f32, ocml
-                                        trig, v_med3_f32) -- the output is bit-identical to the reference's own OpenCL kernels
-                                        compiled for gfx950 (tests/test_gpu_reference_kernels.py).
-                                        Flag set: correctly rounded forms every IEEE machine reproduces -- what the CPU oracle
-                                        computes; differs from the default by <= 1-2 ulp in those leaf functions, which the
-                                        stochastic programs' random() can amplify into a flipped ray decision in ~0.03 % of
-                                        pixels. */,
-  LT_RENDER_FLAG_AS_SHIPPED_MATH = 16u /* The default flavour matches the reference kernels built with -ffp-contract=off
-                                        -cl-fp32-correctly-rounded-divide-sqrt.  This one matches them as RendererOpenCL builds
-                                        them -- clBuildProgram with NULL options (src/opencl/renderer_opencl.cpp:50): `a*b + c` of
-                                        one source expression fused, float divide / sqrt at the OpenCL default accuracy
-                                        (v_rcp_f32 / v_sqrt_f32 based) -- bit for bit on this GPU with this ROCm's OpenCL
-                                        compiler.  Not with the counter flags, not for user programs. */
+  LT_RENDER_FLAG_DEVICE_LIBM = 4u,   /* accepted and ignored (ABI 2 name of what became LT_RENDER_FLAG_STRICT_MATH) */
+  /* Floating-point flavour ("Floating-point model"): what the reference leaves to its OpenCL implementation.
+   * DEFAULT (no flag): the reference's kernel files exactly as RendererOpenCL builds them on this GPU -- clBuildProgram with
+   *   NULL options (src/opencl/renderer_opencl.cpp:50): `a*b + c` inside one source expression is one fused multiply-add,
+   *   float divide / sqrt have the OpenCL default accuracy (v_rcp_f32 / v_sqrt_f32 based), the builtins (dot, cross,
+   *   normalize, distance, sin, cos, clamp) are ROCm's OpenCL device library's.  Output is bit-identical to those kernels
+   *   (tests/test_gpu_reference_kernels.py, test_gpu_full_size.py, test_gpu_configs.py).
+   * LT_RENDER_FLAG_STRICT_MATH: the same kernels built with -ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt: one IEEE
+   *   operation per source operation outside the builtins.  Bit-identical to that build.
+   * LT_RENDER_FLAG_PORTABLE_MATH: strict, and the four builtin leaf functions where the device library uses hardware
+   *   approximations (rsqrt, sqrt, sinf / cosf, clamp) in correctly rounded forms every IEEE machine reproduces: what the CPU
+   *   oracle computes.  Differs from STRICT by <= 1-2 ulp in those functions, which the stochastic programs' random() can
+   *   amplify into a flipped ray decision in ~0.03 % of pixels.
+   * PORTABLE and STRICT exclude each other. */
+  LT_RENDER_FLAG_PORTABLE_MATH = 8u,
+  LT_RENDER_FLAG_STRICT_MATH = 16u
 };
 
 typedef struct lt_hip_render_desc {

@@ -16,9 +16,9 @@ PROGRAM_CUSTOM_OPENCL = 5
 KERNEL_MODE_LINEAR, KERNEL_MODE_TILE = 0, 1
 RENDER_FLAG_STATS = 1
 RENDER_FLAG_PIXEL_COUNTERS = 2
-RENDER_FLAG_DEVICE_LIBM = 4      # ignored since ABI 3 (it is the default flavour)
+RENDER_FLAG_DEVICE_LIBM = 4      # ignored (ABI 2 name of RENDER_FLAG_STRICT_MATH)
 RENDER_FLAG_PORTABLE_MATH = 8
-RENDER_FLAG_AS_SHIPPED_MATH = 16
+RENDER_FLAG_STRICT_MATH = 16
 
 # every symbol include/lenstrace_hip.h declares
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",
@@ -94,7 +94,7 @@ def load():
     for name in EXPORTS:
         if name not in ("lt_hip_last_error",):
             getattr(L, name).restype = i32
-    if L.lt_hip_abi_version() != 3:
+    if L.lt_hip_abi_version() != 4:
         raise ImportError("liblenstrace-hip.so ABI version mismatch")
     _lib = L
     return L

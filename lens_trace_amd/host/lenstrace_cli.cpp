@@ -7,7 +7,7 @@
 //   output   { file_path }
 // with "RENDER_PLATFORM_HIP" as the platform (OPENCL / CUDA scene files are accepted too: their kernel_file_path selects the
 // built-in program by basename) and one optional extension object for the device-side progressive loop:
-//   hip { frame_first, frame_count, accumulate, gi_max_depth, device, portable_math, bvh: "median" | "sah" }
+//   hip { frame_first, frame_count, accumulate, gi_max_depth, device, portable_math, strict_math, bvh: "median" | "sah" }
 // Output: .jpg (the reference's format: ImageWriter, value*255 narrowed to 8 bits, quality 100; image_writer.cpp holds the
 // encoder), .pfm (float RGB, bottom-up as the format demands), .ppm (8-bit, same narrowing), .raw (the float buffer as is).
 // The JSON reader below is a ~100-line recursive-descent parser written for this file (objects, arrays, strings, numbers,
@@ -125,6 +125,7 @@ struct SceneConfig {   // defaults of the reference's SceneParser
   uint32_t frameFirst = 0, frameCount = 0, accumulate = 0;
   int giMaxDepth = 0, device = 0;
   bool sah = false;            // default: the reference's median-split builder
+  bool strictMath = false;
   bool portableMath = false;   // default: the reference kernels' own math on this GPU (BackendPropertiesHIP)
 };
 
@@ -164,6 +165,7 @@ bool loadScene(const std::string& path, SceneConfig& c, std::string& error) {
     if (const Json* v = h->find("accumulate")) c.accumulate = v->kind == Json::Bool ? v->boolean : (v->number != 0);
     c.giMaxDepth = (int)num(h->find("gi_max_depth"), 0);
     if (const Json* v = h->find("bvh")) c.sah = v->string == "sah";
+    if (const Json* v = h->find("strict_math")) c.strictMath = v->kind == Json::Bool ? v->boolean : (v->number != 0);
     if (const Json* v = h->find("portable_math")) c.portableMath = v->kind == Json::Bool ? v->boolean : (v->number != 0);
     c.device = (int)num(h->find("device"), 0);
   }
@@ -274,9 +276,10 @@ int main(int argc, const char** argv) {
     rp.pNext = &pp;
   }
   BackendPropertiesHIP bp = {};
-  if (cfg.portableMath) {
+  if (cfg.portableMath || cfg.strictMath) {
     bp.sType = STRUCTURE_TYPE_BACKEND_PROPERTIES_HIP;
-    bp.portableMath = 1;
+    bp.portableMath = cfg.portableMath ? 1 : 0;
+    bp.strictMath = cfg.strictMath ? 1 : 0;
     bp.pNext = rp.pNext;
     rp.pNext = &bp;
   }

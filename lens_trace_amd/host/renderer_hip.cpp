@@ -106,7 +106,7 @@ void RendererHIP::render(void* pRenderProperties) {
     desc.gi_max_depth = progressive->giMaxDepth;
   }
   if (backend && backend->portableMath) desc.flags |= LT_RENDER_FLAG_PORTABLE_MATH;
-  if (backend && backend->asShippedMath) desc.flags |= LT_RENDER_FLAG_AS_SHIPPED_MATH;
+  if (backend && backend->strictMath) desc.flags |= LT_RENDER_FLAG_STRICT_MATH;
   if (lt_hip_render(context, &desc, (float*)props->pOutputBuffer, props->outputBufferSize) != LT_OK) {
     printf("Kernel Error: %s\n", lt_hip_last_error(context));
   }

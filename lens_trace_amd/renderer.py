@@ -41,12 +41,12 @@ class RenderPropertiesHIP:
     giMaxDepth: int = 0
     collectStats: bool = False
     pixelCounters: bool = False                  # diagnostic: per-pixel work counters instead of colour (depth >= 4)
-    # Floating-point flavour of rsqrt / sqrt / sinf / cosf / clamp.  Default: what ROCm's OpenCL device
-    # library gives the reference kernels on this GPU -- bit-identical to them.  True: the correctly rounded forms the CPU
-    # oracle reproduces (oracle comparisons use this).
+    # Floating-point flavour.  Default: the reference's kernel files as RendererOpenCL builds them on this
+    # GPU (clBuildProgram with NULL options) -- bit-identical to them.  strictMath: the same kernels built with
+    # -ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt.  portableMath: strict, with the device library's approximate
+    # leaf functions (rsqrt, sqrt, sinf, cosf, clamp) in correctly rounded forms -- what the CPU oracle computes.
     portableMath: bool = False
-    # ... or the reference kernels as RendererOpenCL builds them (NULL build options: fused a*b+c, 2.5-ulp divide / sqrt)
-    asShippedMath: bool = False
+    strictMath: bool = False
     # 0: every render() hands the scene buffers to lt_hip_set_scene, which hashes them in full and uploads only when the
     # content changed (the reference uploads on every call).  != 0: the caller versions its scene; the buffers are looked at
     # again only when the objects or this number change.
@@ -54,7 +54,7 @@ class RenderPropertiesHIP:
 
 
 def make_desc(program, W, H, depth, camera28, kernel_mode=KERNEL_MODE_LINEAR, frame_first=0, frame_count=0,
-              accumulate=False, accumulate_base=0, tile=None, gi_max_depth=0, stats=False, pixel_counters=False, portable_math=False, as_shipped_math=False):
+              accumulate=False, accumulate_base=0, tile=None, gi_max_depth=0, stats=False, pixel_counters=False, portable_math=False, strict_math=False):
     d = C.RenderDesc()
     d.struct_size = ctypes.sizeof(C.RenderDesc)
     d.program, d.kernel_mode = program, kernel_mode
@@ -69,7 +69,7 @@ def make_desc(program, W, H, depth, camera28, kernel_mode=KERNEL_MODE_LINEAR, fr
         d.tile_w, d.tile_h, d.tile_first, d.tile_stride = tile
     d.gi_max_depth = gi_max_depth
     d.flags = ((C.RENDER_FLAG_STATS if stats else 0) | (C.RENDER_FLAG_PIXEL_COUNTERS if pixel_counters else 0) |
-               (C.RENDER_FLAG_PORTABLE_MATH if portable_math else 0) | (C.RENDER_FLAG_AS_SHIPPED_MATH if as_shipped_math else 0))
+               (C.RENDER_FLAG_PORTABLE_MATH if portable_math else 0) | (C.RENDER_FLAG_STRICT_MATH if strict_math else 0))
     return d
 
 
@@ -139,7 +139,7 @@ class RendererHIP:
             self._scene_version = props.sceneVersion
         program = self.resolve_program(props.kernelFilePath)
         d = make_desc(program, W, H, D, props.pCamera, props.kernelMode, props.frameFirst, props.frameCount,
-                      props.accumulate, props.accumulateBase, None, props.giMaxDepth, props.collectStats, props.pixelCounters, props.portableMath, props.asShippedMath)
+                      props.accumulate, props.accumulateBase, None, props.giMaxDepth, props.collectStats, props.pixelCounters, props.portableMath, props.strictMath)
         self._check(self._L.lt_hip_render(self._ctx, ctypes.byref(d), out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
 
     # -- device-resident variants (bench / multi-GPU) -----------------------------------------------------

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(C.EXPORTS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.lt_hip_abi_version() == 3
+    assert L.lt_hip_abi_version() == 4
 
 
 @pytest.mark.parametrize("path,prog", [

@@ -68,25 +68,27 @@ def test_config2_cornell_global_illumination_1080p(renderer):
 def test_config2_full_frame_matches_reference_gi_kernel(renderer, monkeypatch):
     """BASELINE config 2 at its stated size against the reference's own global_illumination.cl
     (examples/global_illumination/resources/kernels/global_illumination.cl:241-375; its bounce count is the constant 16)
-    compiled for gfx950: the default flavour, both GI execution paths, bit for bit over the 1920x1080 frame."""
+    compiled for gfx950 with the reference's NULL build options: the default flavour, both GI execution paths, bit for bit over
+    the 1920x1080 frame; and the strict flavour against the strict build of the same file."""
     from lens_trace_amd.renderer import RenderPropertiesHIP as DefaultFlavourProps
     from oracle import ref_gpu
-    if not ref_gpu.available("global_illumination"):
-        pytest.skip("oracle/_ref/global_illumination.strict.co not built (needs /root/reference at build time)")
+    if not ref_gpu.available("global_illumination", "default"):
+        pytest.skip("oracle/_ref/global_illumination.default.co not built (needs /root/reference at build time)")
     s = sc.load_ltsb(os.path.join(GOLDEN, "cornell_box_O0.ltsb")).validate()
     W, H = 1920, 1080
     cam = sc.camera_with_frame(s.camera, 2)
-    ref = ref_gpu.render(s, cam, W, H, "global_illumination", "strict")
-    for mega in ("0", "1"):
-        monkeypatch.setenv("LT_GI_MEGAKERNEL", mega)
-        got = np.empty((H, W, 3), dtype=np.float32)
-        renderer.render(DefaultFlavourProps(GI, (W, H, 3), got, s, pCamera=cam))
-        ndiff = int((got != ref).sum())
-        assert ndiff == 0, "LT_GI_MEGAKERNEL=%s: %d of %d floats differ from the reference kernel" % (mega, ndiff, ref.size)
+    for build in ("default", "strict"):
+        ref = ref_gpu.render(s, cam, W, H, "global_illumination", build)
+        for mega in ("0", "1"):
+            monkeypatch.setenv("LT_GI_MEGAKERNEL", mega)
+            got = np.empty((H, W, 3), dtype=np.float32)
+            renderer.render(DefaultFlavourProps(GI, (W, H, 3), got, s, pCamera=cam, strictMath=(build == "strict")))
+            ndiff = int((got != ref).sum())
+            assert ndiff == 0, "%s build, LT_GI_MEGAKERNEL=%s: %d of %d floats differ from the reference kernel" % (build, mega, ndiff, ref.size)
     # and the running mean of 4 frames through the fused pipeline == the reference's frames folded in float32
     acc = None
     for k in range(4):
-        c = ref_gpu.render(s, sc.camera_with_frame(s.camera, 1 + k), W, H, "global_illumination", "strict")
+        c = ref_gpu.render(s, sc.camera_with_frame(s.camera, 1 + k), W, H, "global_illumination", "default")
         acc = c if k == 0 else ((c + acc * np.float32(k)) / np.float32(k + 1)).astype(np.float32)
     monkeypatch.delenv("LT_GI_MEGAKERNEL")
     got = np.empty((H, W, 3), dtype=np.float32)

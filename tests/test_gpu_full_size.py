@@ -150,22 +150,23 @@ def test_tile_mode_clamped_equals_linear_mode(renderer, wall):
 
 
 # ---- the timed kernel against the reference itself, at full size --------------------------------------------------------
-@pytest.mark.parametrize("yaw", [0.0, 0.03])
-def test_whole_4k_frame_matches_reference_accumulator_kernel(renderer, wall, monkeypatch, yaw):
+@pytest.mark.parametrize("yaw,build", [(0.0, "default"), (0.03, "default"), (0.0, "strict")])
+def test_whole_4k_frame_matches_reference_accumulator_kernel(renderer, wall, monkeypatch, yaw, build):
     """examples/accumulator/resources/kernels/accumulator.cl:113-217 (one work-item per pixel, private 64-entry stack) on the
-    1 002 530-triangle buffers at 3840x2160 against the HIP path's default flavour: packet walks over pair records, octant
-    switches, the 20-row LDS stack, slow-path squares first, both shadow-ray walks.  Bit for bit."""
+    1 002 530-triangle buffers at 3840x2160, built with the reference's own (NULL) build options, against the HIP path's default
+    flavour -- the kernel bench.py times: packet walks over pair records, octant switches, the 20-row LDS stack, slow-path
+    squares first, both shadow-ray walks.  Bit for bit.  (And the strict flavour against the strict build of the same file.)"""
     from lens_trace_amd.renderer import RenderPropertiesHIP as DefaultFlavourProps
     from oracle import ref_gpu
-    if not ref_gpu.available("accumulator"):
-        pytest.skip("oracle/_ref/accumulator.strict.co not built (needs /root/reference at build time)")
+    if not ref_gpu.available("accumulator", build):
+        pytest.skip("oracle/_ref/accumulator.%s.co not built (needs /root/reference at build time)" % build)
     cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, 2)
-    ref = ref_gpu.render(wall, cam, W, H, "accumulator", "strict")
+    ref = ref_gpu.render(wall, cam, W, H, "accumulator", build)
     assert ref.shape == (H, W, 3) and ref.sum() > 0
     for packets in ("1", "0"):
         monkeypatch.setenv("LT_SHADOW_PACKETS", packets)
         got = np.empty((H, W, 3), dtype=np.float32)
-        renderer.render(DefaultFlavourProps(ACC, (W, H, 3), got, wall, pCamera=cam))
+        renderer.render(DefaultFlavourProps(ACC, (W, H, 3), got, wall, pCamera=cam, strictMath=(build == "strict")))
         assert renderer.stats()["shadow_packets"] == int(packets)
         ndiff = int((got != ref).sum())
-        assert ndiff == 0, "yaw %g, LT_SHADOW_PACKETS=%s: %d of %d floats differ from the reference kernel" % (yaw, packets, ndiff, ref.size)
+        assert ndiff == 0, "%s build, yaw %g, LT_SHADOW_PACKETS=%s: %d of %d floats differ from the reference kernel" % (build, yaw, packets, ndiff, ref.size)

@@ -5,15 +5,16 @@ basic_lighting, global_illumination, lens), and the traversal machinery the benc
 child-pair records, any-hit shadow packets, per-XCD persistent queues, fused multi-sample launches) against
 examples/accumulator/resources/kernels/accumulator.cl:113-217 itself rather than against the CPU restatement.
 
-Against the "strict" build (-ffp-contract=off, correctly rounded divide/sqrt) the HIP path in its DEFAULT flavour --
-what RendererHIP::render, the Python mirror, the CLI and bench.py run -- must be BIT-IDENTICAL (asserted: RMS <= 1e-4,
-north_star, and zero differing floats).  The portable flavour (LT_RENDER_FLAG_PORTABLE_MATH, the one the CPU oracle
-reproduces) differs from the reference kernels by <= 1-2 ulp in four leaf functions; that gap is asserted too:
-<= 1e-4 RMS for the programs without random() amplification, a bound on the flipped pixels for the others.
+Three builds of the path are compared with two builds of the reference's kernels:
 
-Against the reference's as-shipped build options (NULL: contraction allowed, approximate divide/sqrt;
-src/opencl/renderer_opencl.cpp:50) the difference is reported for all six programs and asserted only for the programs
-whose expressions have no contractable a*b+c on a decision path."""
+* the HIP path's DEFAULT flavour -- what RendererHIP::render, the Python mirror, the CLI and bench.py run -- against the
+  reference's kernels built AS THE REFERENCE BUILDS THEM: clBuildProgram with NULL options
+  (src/opencl/renderer_opencl.cpp:50; oracle/_ref/*.default.co).  BIT-IDENTICAL: zero differing floats, all six programs;
+* the strict flavour (LT_RENDER_FLAG_STRICT_MATH) against the same kernels built with -ffp-contract=off
+  -cl-fp32-correctly-rounded-divide-sqrt (*.strict.co): BIT-IDENTICAL;
+* the portable flavour (LT_RENDER_FLAG_PORTABLE_MATH, the one the CPU oracle reproduces) differs from the strict build by
+  <= 1-2 ulp in four leaf functions; that gap is asserted: <= 1e-4 RMS (north_star) for the programs without random()
+  amplification, a bound on the flipped pixels for the others."""
 import os
 
 import numpy as np
@@ -98,11 +99,11 @@ def test_hip_matches_reference_kernel_strict(renderer, monkeypatch, scene, kerne
     s = sc.load_ltsb(os.path.join(GOLDEN, scene + ".ltsb")).validate()
     cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, frame)
     ref = ref_gpu.render(s, cam, W, H, kernel, "strict", mode)
-    got = hip(renderer, s, kernel, W, H, cam, mode)                       # the default flavour: what every caller gets
+    got = hip(renderer, s, kernel, W, H, cam, mode, strictMath=True)      # the strict flavour
     port = hip(renderer, s, kernel, W, H, cam, mode, portableMath=True)   # the CPU oracle's flavour
     nbits = int((got != ref).sum())
     poff = pixels_off(port, ref)
-    print("REF-strict %s/%s m%d %dx%d f%d: default rms=%.3g floats_differing=%d/%d | portable rms=%.3g pixels_off_by_1e-4=%d (bound %d)" % (
+    print("REF-strict %s/%s m%d %dx%d f%d: strict rms=%.3g floats_differing=%d/%d | portable rms=%.3g pixels_off_by_1e-4=%d (bound %d)" % (
         scene, kernel, mode, W, H, frame, rms(got, ref), nbits, ref.size, rms(port, ref), poff, portable_pixel_bound(kernel, W * H)))
     assert ref.sum() > 0
     assert rms(got, ref) <= RMS_TOL
@@ -113,66 +114,40 @@ def test_hip_matches_reference_kernel_strict(renderer, monkeypatch, scene, kerne
     assert poff <= portable_pixel_bound(kernel, W * H)
 
 
-DEFAULT_CASES = [  # one per program + the lens path + a tile-mode case
+DEFAULT_CASES = [  # scene, kernel, mode, W, H, frame[, yaw]: every program, the lens path, both kernel modes, yaw != 0
     ("green_wall_O0", "basic", 0, 100, 100, 0),
     ("cornell_box_O0", "basic", 0, 128, 128, 0),
+    ("cornell_box_O0", "basic", 1, 128, 128, 0),
     ("cornell_box_lens_O0", "basic", 0, 128, 128, 0),
     ("cornell_box_O0", "custom_opencl", 0, 128, 128, 0),
+    ("cornell_box_lens_O0", "custom_opencl", 0, 128, 128, 0),
     ("cornell_box_O0", "accumulator", 0, 128, 128, 0),
+    ("cornell_box_O0", "accumulator", 0, 256, 256, 5),
     ("cornell_box_O0", "accumulator", 1, 128, 128, 7),
     ("cornell_box_O0", "basic_lighting", 0, 64, 64, 1),
+    ("cornell_box_O0", "basic_lighting", 1, 64, 64, 0, 0.01),
     ("cornell_box_O0", "global_illumination", 0, 128, 128, 0),
     ("cornell_box_O0", "global_illumination", 0, 256, 256, 3),
     ("cornell_box_O0", "global_illumination25", 0, 64, 64, 2),
-]
-
-
-@pytest.mark.parametrize("scene,kernel,mode,W,H,frame", DEFAULT_CASES)
-def test_report_against_default_build_options(renderer, scene, kernel, mode, W, H, frame):
-    """The reference passes NULL build options (renderer_opencl.cpp:50), which lets the OpenCL compiler contract a*b+c
-    and use approximate divide/sqrt: which expressions it contracts is the compiler's choice of the day, so the contract
-    fixed here is the strict build.  Reported for all six programs; asserted at 1e-4 RMS for `basic`
-    (its colour is a material constant: only a flipped hit shows), and bounded in flipped pixels elsewhere (4 x the strict
-    build's portable-flavour bound) so that a regression of the default flavour shows.  Round 2 on the MI355X: basic 0 px,
-    lens 2 px, custom_opencl 1 px, accumulator 1 px, basic_lighting 1 px of 64^2, GI 20 px of 128^2 / 51 px of 256^2,
-    GI-25 41 px of 64^2."""
-    s = sc.load_ltsb(os.path.join(GOLDEN, scene + ".ltsb")).validate()
-    cam = sc.camera_bytes(0.0, 2.5, -50.0, 0.0, 0.0, 0.0, frame)
-    ref = ref_gpu.render(s, cam, W, H, kernel, "default", mode)
-    got = hip(renderer, s, kernel, W, H, cam, mode)
-    poff = pixels_off(got, ref)
-    print("REF-default %s/%s m%d %dx%d f%d: rms=%.3g pixels_off_by_1e-4=%d floats_differing=%d/%d" % (
-        scene, kernel, mode, W, H, frame, rms(got, ref), poff, int((got != ref).sum()), ref.size))
-    if kernel == "basic" and scene != "cornell_box_lens_O0":   # lens: refract() has contractable a*b+c chains
-        assert rms(got, ref) <= RMS_TOL                        # (custom_opencl's colour IS (u, v, 1-u-v): contraction inside
-                                                               #  intersectTriangle shows in every float, and flips an edge pixel)
-    else:
-        assert poff <= 4 * (2 + W * H // (100 if kernel in ("basic_lighting", "global_illumination25") else 1000))
-
-
-SHIPPED_CASES = DEFAULT_CASES + [
-    ("cornell_box_O0", "basic", 1, 128, 128, 0, 0.0),
-    ("cornell_box_lens_O0", "custom_opencl", 0, 128, 128, 0, 0.0),
-    ("cornell_box_O0", "accumulator", 0, 96, 64, 3, 0.02),          # yaw != 0: the fused rotation
+    ("cornell_box_O0", "accumulator", 0, 96, 64, 3, 0.02),          # yaw != 0: the fused rotation, cos / sin per work-item
     ("cornell_box_O0", "global_illumination", 0, 96, 64, 1, -0.015),
-    ("cornell_box_O0", "basic_lighting", 1, 64, 64, 0, 0.01),
 ]
-SHIPPED_CASES = [c if len(c) == 7 else c + (0.0,) for c in SHIPPED_CASES]
+DEFAULT_CASES = [c if len(c) == 7 else c + (0.0,) for c in DEFAULT_CASES]
 
 
-@pytest.mark.parametrize("scene,kernel,mode,W,H,frame,yaw", SHIPPED_CASES)
-def test_as_shipped_flavour_matches_reference_default_build(renderer, monkeypatch, scene, kernel, mode, W, H, frame, yaw):
-    """LT_RENDER_FLAG_AS_SHIPPED_MATH (asShippedMath) against the reference's kernels built the way RendererOpenCL builds them --
-    clBuildProgram with NULL options (src/opencl/renderer_opencl.cpp:50): contraction of a*b+c inside expressions, 2.5-ulp
-    divide, 3-ulp sqrt -- all six programs, both kernel modes, both GI execution paths: BIT-IDENTICAL."""
+@pytest.mark.parametrize("scene,kernel,mode,W,H,frame,yaw", DEFAULT_CASES)
+def test_default_flavour_matches_the_reference_as_it_builds_its_kernels(renderer, monkeypatch, scene, kernel, mode, W, H, frame, yaw):
+    """The DEFAULT flavour against the reference's kernels built the way RendererOpenCL builds them -- clBuildProgram with NULL
+    options (src/opencl/renderer_opencl.cpp:50): contraction of a*b+c inside expressions, 2.5-ulp divide, 3-ulp sqrt -- all six
+    programs, both kernel modes, both GI execution paths: BIT-IDENTICAL."""
     if "global_illumination" in kernel:
         monkeypatch.setenv("LT_GI_MEGAKERNEL", "0" if frame % 2 else "1")
     s = sc.load_ltsb(os.path.join(GOLDEN, scene + ".ltsb")).validate()
     cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, frame)
     ref = ref_gpu.render(s, cam, W, H, kernel, "default", mode)
-    got = hip(renderer, s, kernel, W, H, cam, mode, asShippedMath=True)
+    got = hip(renderer, s, kernel, W, H, cam, mode)
     nbits = int((got != ref).sum())
-    print("REF-as-shipped %s/%s m%d %dx%d f%d yaw %g: rms=%.3g floats_differing=%d/%d pixels_off_by_1e-4=%d" % (
+    print("REF-default %s/%s m%d %dx%d f%d yaw %g: rms=%.3g floats_differing=%d/%d pixels_off_by_1e-4=%d" % (
         scene, kernel, mode, W, H, frame, yaw, rms(got, ref), nbits, ref.size, pixels_off(got, ref)))
     assert ref.sum() > 0
     assert nbits == 0
@@ -193,18 +168,19 @@ def synth_scene(name):
 @pytest.mark.parametrize("packets", ["0", "1"])
 @pytest.mark.parametrize("name,frame,yaw", [("wall", 1, 0.0), ("wall", 6, 0.03), ("soup", 2, 0.0), ("soup", 3, -0.02), ("blob", 1, 0.0),
                                             ("blob", 4, 0.05)])
-def test_big_scenes_both_shadow_walks_match_reference_accumulator(renderer, monkeypatch, name, frame, yaw, packets):
+@pytest.mark.parametrize("build", ["default", "strict"])
+def test_big_scenes_both_shadow_walks_match_reference_accumulator(renderer, monkeypatch, name, frame, yaw, packets, build):
     """Packet walks, pair records, octant switches, any-hit shadow packets (LT_SHADOW_PACKETS=1) and the per-lane walk (=0),
     image-centre row / column squares included (256 is even), against accumulator.cl's own traversal."""
     monkeypatch.setenv("LT_SHADOW_PACKETS", packets)
     s = synth_scene(name)
     W = H = 256
     cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, frame)
-    ref = ref_gpu.render(s, cam, W, H, "accumulator", "strict")
-    got = hip(renderer, s, "accumulator", W, H, cam)
+    ref = ref_gpu.render(s, cam, W, H, "accumulator", build)
+    got = hip(renderer, s, "accumulator", W, H, cam, strictMath=(build == "strict"))
     assert ref.sum() > 0
-    assert int((got != ref).sum()) == 0, "%s f%d yaw %g packets %s: %d floats differ, rms %.3g" % (
-        name, frame, yaw, packets, int((got != ref).sum()), rms(got, ref))
+    assert int((got != ref).sum()) == 0, "%s f%d yaw %g packets %s %s: %d floats differ, rms %.3g" % (
+        name, frame, yaw, packets, build, int((got != ref).sum()), rms(got, ref))
 
 
 @pytest.mark.parametrize("packets", ["0", "1"])
@@ -217,7 +193,7 @@ def test_fused_running_mean_matches_reference_frames_folded(renderer, monkeypatc
     W, H, first, count = 200, 136, 3, 5
     acc = None
     for k in range(count):
-        c = ref_gpu.render(s, sc.camera_bytes(0.0, 2.5, -50.0, 0.0, 0.0, 0.0, first + k), W, H, "accumulator", "strict")
+        c = ref_gpu.render(s, sc.camera_bytes(0.0, 2.5, -50.0, 0.0, 0.0, 0.0, first + k), W, H, "accumulator", "default")
         acc = c if k == 0 else ((c + acc * np.float32(k)) / np.float32(k + 1)).astype(np.float32)
     got = hip(renderer, s, "accumulator", W, H, sc.camera_bytes(0.0, 2.5, -50.0), frameFirst=first, frameCount=count, accumulate=True)
     assert renderer.stats()["kernel_launches"] <= 3      # one fused render launch (+ its twin when the walk is being timed) + the fold
@@ -229,8 +205,9 @@ def test_global_illumination_pipeline_on_a_big_scene_matches_reference(renderer,
     s = synth_scene("wall")
     W = H = 128
     cam = sc.camera_bytes(0.0, 2.5, -50.0, 0.01, 0.0, 0.0, 2)
-    ref = ref_gpu.render(s, cam, W, H, "global_illumination", "strict")
-    for mega in ("0", "1"):
-        monkeypatch.setenv("LT_GI_MEGAKERNEL", mega)
-        got = hip(renderer, s, "global_illumination", W, H, cam)
-        assert int((got != ref).sum()) == 0, "LT_GI_MEGAKERNEL=%s: rms %.3g" % (mega, rms(got, ref))
+    for build in ("default", "strict"):
+        ref = ref_gpu.render(s, cam, W, H, "global_illumination", build)
+        for mega in ("0", "1"):
+            monkeypatch.setenv("LT_GI_MEGAKERNEL", mega)
+            got = hip(renderer, s, "global_illumination", W, H, cam, strictMath=(build == "strict"))
+            assert int((got != ref).sum()) == 0, "%s LT_GI_MEGAKERNEL=%s: rms %.3g" % (build, mega, rms(got, ref))
