@@ -10,6 +10,7 @@ from lens_trace_amd import _capi as C
 from lens_trace_amd import scene as sc
 from lens_trace_amd.renderer import KERNEL_MODE_TILE, RendererHIP
 from oracle import pyoracle as po
+from tests.conftest import fuzz_scene
 from tests.conftest import oracle_props as RenderPropertiesHIP   # the flavour the CPU oracle reproduces
 
 pytestmark = pytest.mark.gpu
@@ -169,27 +170,7 @@ def test_axis_parallel_and_degenerate_rays(renderer):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LT_FUZZ_SEEDS", "12"))))   # LT_FUZZ_SEEDS=300 for a long soak
 def test_fuzz_random_scenes(renderer, monkeypatch, seed):
     monkeypatch.setenv("LT_GI_MEGAKERNEL", str(seed % 2))       # alternate the two GI execution paths
-    rng = np.random.default_rng(1000 + seed)
-    n = int(rng.integers(1, 400))
-    centre = np.stack([rng.uniform(-4, 4, n), rng.uniform(-1.5, 6.5, n), rng.uniform(-6, 1, n)], axis=-1)
-    size = 10.0 ** rng.uniform(-1.5, 0.3)
-    pos = (centre[:, None, :] + rng.normal(0, size, (n, 3, 3))).astype(np.float32)
-    nrm = rng.normal(0, 1, (n, 3, 3)).astype(np.float32)
-    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
-    k = int(rng.integers(2, 6))
-    m = np.zeros(k, dtype=sc.MATERIAL_DTYPE)
-    m["diffuse"] = rng.uniform(0, 1, (k, 3))
-    m["ior"] = rng.uniform(1.0, 2.0, k)
-    m["dissolve"] = np.where(rng.uniform(0, 1, k) < 0.25, 0.25, 1.0)     # some lens materials (basic's refraction path)
-    m[k - 1]["emission"] = (1, 1, 1)
-    m[k - 1]["dissolve"] = 1.0
-    mi = rng.integers(0, k, n).astype(np.int32)
-    if n > 1:
-        mi[0] = 0                                                           # keep the first triangle non-emissive most of the time
-    s = sc.build_from_triangles(pos, nrm, mi, m).validate()
-    cam = sc.camera_bytes(float(rng.uniform(-1, 1)), float(rng.uniform(1.5, 3.5)), float(rng.uniform(-60, -20)),
-                          float(rng.uniform(-0.03, 0.03)), 0.0, 0.0, int(rng.integers(0, 100)))
-    W, H = int(rng.integers(1, 70)), int(rng.integers(1, 50))
+    s, cam, W, H, rng = fuzz_scene(seed)
     for prog in ("basic", "accumulator", "global_illumination"):
         both(renderer, s, prog, W, H, cam, mode=int(rng.integers(0, 2)), counters=(seed % 3 == 0))
     if seed % 4 == 0:

@@ -24,7 +24,7 @@ from lens_trace_amd import scene as sc
 from lens_trace_amd import synth
 from lens_trace_amd.renderer import RendererHIP, RenderPropertiesHIP
 from oracle import ref_gpu
-from tests.conftest import GOLDEN
+from tests.conftest import GOLDEN, fuzz_scene
 
 pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-4
@@ -211,3 +211,24 @@ def test_global_illumination_pipeline_on_a_big_scene_matches_reference(renderer,
             monkeypatch.setenv("LT_GI_MEGAKERNEL", mega)
             got = hip(renderer, s, "global_illumination", W, H, cam, strictMath=(build == "strict"))
             assert int((got != ref).sum()) == 0, "%s LT_GI_MEGAKERNEL=%s: rms %.3g" % (build, mega, rms(got, ref))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LT_FUZZ_SEEDS", "12"))))   # LT_FUZZ_SEEDS=300 for a long soak
+def test_fuzz_random_scenes_against_the_reference_kernels(renderer, monkeypatch, seed):
+    """The seeded random scenes of tests/test_gpu_edge_cases.py (degenerate and sliver triangles, lens materials, random
+    cameras, odd image sizes, both kernel modes) through the reference's own kernel files on this GPU: the default flavour
+    against the NULL-options build, the strict flavour against the strict build, float for float."""
+    monkeypatch.setenv("LT_GI_MEGAKERNEL", str(seed % 2))       # alternate the two GI execution paths
+    s, cam, W, H, rng = fuzz_scene(seed)
+    mode = int(rng.integers(0, 2))
+    kernels = ["basic", "accumulator", "global_illumination", "custom_opencl"]
+    if seed % 4 == 0:
+        kernels += ["basic_lighting", "global_illumination25"]
+    for kernel in kernels:
+        w, h = (min(W, 24), min(H, 16)) if kernel in ("basic_lighting", "global_illumination25") else (W, H)
+        for build in ("default", "strict"):
+            ref = ref_gpu.render(s, cam, w, h, kernel, build, mode=mode)
+            got = hip(renderer, s, kernel, w, h, cam, mode, strictMath=(build == "strict"))
+            # NaN pixels (a degenerate triangle's 0/0) must be NaN in both; everything else equal as bits
+            same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+            assert same.all(), "seed %d %s %s build mode %d %dx%d: %d floats differ" % (seed, kernel, build, mode, w, h, int((~same).sum()))
