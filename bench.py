@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+SHADOW_WALKS = {0: "per lane", 1: "any-hit packets", 2: "chosen per wavefront"}   # lt_hip_stats.shadow_packets
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -106,7 +107,7 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--cells", type=int, default=708, help="height-field cells per side (708 -> 1 002 530 triangles)")
-    ap.add_argument("--scene", default="wall", choices=["wall", "soup", "blob", "colonnade", "cornell"])
+    ap.add_argument("--scene", default="wall", choices=["wall", "soup", "blob", "colonnade", "cornell", "mixed"])
     ap.add_argument("--program", default="accumulator")
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--bvh", default="median", choices=["median", "sah"], help="split rule of the scene's BVH (same 32-byte node layout): "
@@ -126,6 +127,8 @@ def build_scene(args):
         return synth.triangle_soup(2 * args.cells * args.cells), "synthetic triangle soup (seed 1)"
     if args.scene == "blob":
         return synth.blob_in_box(), "synthetic blob in a box"
+    if args.scene == "mixed":
+        return synth.wall_and_soup(), "synthetic wall with a triangle soup in front of its left half"
     if args.scene == "colonnade":
         return synth.colonnade(), "synthetic colonnade"
     return sc.load_ltsb(os.path.join(ROOT, "tests", "golden", "cornell_box_O0.ltsb")), "Cornell box (reference buffers)"
@@ -290,7 +293,7 @@ def main():
                        "tri_tests_per_ray": tris_total / rays_total, "kernel_only_mrays_per_s": round(rays_total * args.steps / kernel_s / 1e6, 2),
                        "frame_ms": round(ms_per_step, 3),
                        # which of its two (pixel-identical) walks the library timed faster for this scene's shadow rays
-                       "shadow_ray_walk": {1: "any-hit packets", 0: "per lane"}.get(shadow_walk, "not timed")},
+                       "shadow_ray_walk": SHADOW_WALKS.get(shadow_walk, "not timed")},
             "roofline": roofline("%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program),
                                  "lt_render_kernel<%s>" % args.program if launches_per_step <= args.spp else "wavefront GI pipeline (all its stage kernels)",
                                  launch_ms, launches_per_step, args.spp, my_alg_bytes_per_launch, world == 1),
@@ -335,7 +338,7 @@ def soup_figure(args, r, program, dev, stream):
     walk = r.stats()["shadow_packets"]
     return {"soup_mrays_per_s": round(st["rays"] * steps / dt / 1e6, 2), "soup_frame_ms": round(dt / steps * 1e3, 3),
             "soup_triangles": soup.n_prims, "soup_node_visits_per_ray": st["node_visits"] / st["rays"],
-            "soup_shadow_ray_walk": {1: "any-hit packets", 0: "per lane"}.get(walk, "not timed")}
+            "soup_shadow_ray_walk": SHADOW_WALKS.get(walk, "not timed")}
 
 
 def cpu_baseline(args, scene, program):

@@ -111,7 +111,7 @@ struct lt_hip_context {
   uint32_t* d_queues = nullptr;      // persistent mode: 8 per-XCD work counters per launch of a call
   uint32_t queue_frames = 0;
   int shadow_mode[6] = {-1, -1, -1, -1, -1, -1};   // per built-in program: shadow rays as any-hit packets (1) or per lane (0); -1 = not timed yet
-  hipEvent_t cal_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t cal_ev[12] = {};
   std::map<std::vector<uint32_t>, int> shadow_modes;   // (program, W, H, tile geometry) -> the walk timed faster for it on the resident scene
   float* d_samples = nullptr;        // un-accumulated sample images of a fused multi-sample launch
   uint64_t d_samples_bytes = 0;
@@ -572,7 +572,7 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   {
     const char* spe = getenv("LT_SHADOW_PACKETS");
     const int timed = ctx->shadow_mode[LT_PROGRAM_ACCUMULATOR];
-    scPrimary.shadowPackets = (CFG::kDeep ? 0u : spe ? (atoi(spe) != 0 ? 1u : 0u) : (timed == 0 ? 0u : 1u));
+    scPrimary.shadowPackets = (CFG::kDeep ? 0u : spe ? (uint32_t)std::max(0, std::min(2, atoi(spe))) : (timed < 0 ? 1u : (uint32_t)timed));
   }
   hipLaunchKernelGGL((lt_gi_primary_kernel<CFG>), dim3(gridA), dim3(kBlock), lds, s, scPrimary, fp, gp, queues);
   LT_HIP_CHECK(ctx, hipGetLastError());
@@ -856,12 +856,17 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   // the scene; shadow_mode[program] keeps the most recent verdict for callers without a geometry of their own: the GI pipeline)
   const std::vector<uint32_t> shadowKey = {(uint32_t)d->program, d->width, d->height, p.tileW, p.tileH, p.tileFirst, p.tileStride};
   int shadowMode = 0;
-  if (spe) shadowMode = atoi(spe) != 0;
+  if (spe) shadowMode = std::max(0, std::min(2, atoi(spe)));
   else if (hasShadowRays) {
     auto it = ctx->shadow_modes.find(shadowKey);
     shadowMode = it == ctx->shadow_modes.end() ? -1 : it->second;
   }
-  sc.shadowPackets = shadowMode > 0 ? 1u : 0u;
+  sc.shadowPackets = shadowMode > 0 ? (uint32_t)shadowMode : 0u;
+  {
+    const char* se = getenv("LT_SHADOW_SPREAD");
+    const float thr = se ? (float)atof(se) : 0.02f;
+    sc.shadowSpread = thr * thr;
+  }
   sc.ldsNodes = sc.ldsTris = 0u;
   sc.fastRcp = 0u;
 
@@ -959,10 +964,10 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
                                                                                             : (deep ? up.deepPortable : up.ldsPortable);
         LT_HIP_CHECK(ctx, hipModuleLaunchKernel(fn, grid.x, 1, 1, kBlock, 1, 1, lds, s, args, nullptr));
       } else {
-        // Time both shadow-ray walks once per (scene, program, image geometry), ahead of a launch whose output they may scribble
-        // on (it overwrites what it writes, as every fused launch does): the launch's FIRST frame alone runs four times --
-        // packets, per lane, packets, per lane -- and each walk is given the faster of its two runs, so the first, cache-cold
-        // launch of a scene and a one-off hiccup decide nothing; then the launch itself runs once, with the winner.
+        // Time the three shadow-ray walks (packets, per lane, chosen per wavefront) once per (scene, program, image geometry), ahead
+        // of a launch whose output they may scribble on (it overwrites what it writes, as every fused launch does): the launch's
+        // FIRST frame alone runs six times -- the three in turn, twice -- and each walk is given the faster of its two runs, so the
+        // first, cache-cold launch of a scene and a one-off hiccup decide nothing; then the launch itself runs once, with the winner.
         const bool calibrate = shadowMode < 0 && persistent && !stats && ctx->bvh_height <= kLdsStack && fp.accumulateN < 0;
         auto launch_render = [&](const FrameParams& fpl, dim3 g) {
           switch (d->program) {
@@ -979,22 +984,26 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
           FrameParams f1 = fp;
           f1.fusedFrames = 1;
           const dim3 g1((uint32_t)std::min<uint64_t>(nblocks, resident));
-          for (int pass = 0; pass < 4; pass++) {
-            sc.shadowPackets = (pass & 1) ? 0u : 1u;
+          static const uint32_t kOrder[3] = {1u, 0u, 2u};
+          for (int pass = 0; pass < 6; pass++) {
+            sc.shadowPackets = kOrder[pass % 3];
             if (pass > 0) LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
             LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass], s));
             launch_render(f1, g1);
             LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass + 1], s));
           }
-          float t[4];
-          LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->cal_ev[7]));
-          for (int k = 0; k < 4; k++) LT_HIP_CHECK(ctx, hipEventElapsedTime(&t[k], ctx->cal_ev[2 * k], ctx->cal_ev[2 * k + 1]));
-          const float packets = std::min(t[0], t[2]), perLane = std::min(t[1], t[3]);
-          shadowMode = packets < 0.99f * perLane ? 1 : 0;   // (a tie keeps the per-lane walk)
+          float t[6];
+          LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->cal_ev[11]));
+          for (int k = 0; k < 6; k++) LT_HIP_CHECK(ctx, hipEventElapsedTime(&t[k], ctx->cal_ev[2 * k], ctx->cal_ev[2 * k + 1]));
+          const float packets = std::min(t[0], t[3]), perLane = std::min(t[1], t[4]), perWave = std::min(t[2], t[5]);
+          float best = perLane;                                  // (ties keep the simpler walk: per lane, then packets)
+          shadowMode = 0;
+          if (packets < 0.99f * best) { shadowMode = 1; best = packets; }
+          if (perWave < 0.99f * best) shadowMode = 2;
           ctx->shadow_modes[shadowKey] = shadowMode;
           ctx->shadow_mode[d->program] = shadowMode;
           sc.shadowPackets = (uint32_t)shadowMode;
-          launches += 4;
+          launches += 6;
           LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
         }
         launch_render(fp, grid);

@@ -64,7 +64,8 @@ struct SceneDev {
   const Material* mats;
   const Lights* lights;
   uint32_t n_nodes, n_prims, n_mats;
-  uint32_t shadowPackets;   // != 0: shadow rays of the non-counting kernels walk as any-hit packets (chosen per scene by the host)
+  uint32_t shadowPackets;   // shadow rays of the non-counting kernels: 0 per lane, 1 as any-hit packets, 2 chosen per wavefront (shadowSpread);
+                            // the host times the three on a scene's first frame (lt_capi.hip)
   // A scene of a few hundred triangles (the Cornell box: 83 nodes + 42 triangles = 4.7 KB) lives in LDS for the per-lane walks of
   // the kernels instantiated with Config::kLdsScene: byte offsets of the workgroup's copies of `nodes` and `tris` in its LDS
   // (filled by the kernel itself, lt_kernel.hpp).  An incoherent per-lane walk is 64 distinct 32-byte fetches per visited node,
@@ -72,6 +73,8 @@ struct SceneDev {
   // reads take that path out of the walk.
   uint32_t ldsNodes, ldsTris;
   uint32_t fastRcp;         // != 0: intersectTriangle's 1 / det as the reference's as-shipped build computes it (Math<2>::rcp), in every walk
+  float shadowSpread;       // shadowPackets == 2: a wave's shadow rays walk as a packet iff every origin lies within sqrt(shadowSpread) x its
+                            // own ray's length of the first lane's origin (one surface patch looking at one light), else per lane
 };
 
 typedef float LdsVec4 __attribute__((ext_vector_type(4)));
@@ -854,7 +857,14 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
   if (__all(finite)) {
     // (not in the global-illumination programs: most of their shadow rays start at bounce hits and are incoherent, and the
     // extra walks cost their register-heavy kernels a third of their speed on small scenes)
-    if (ANYHIT && !DEEP && PROGRAM != kGI && PROGRAM != kGI25 && sc.shadowPackets != 0u) {
+    bool asPacket = ANYHIT && !DEEP && PROGRAM != kGI && PROGRAM != kGI25 && sc.shadowPackets != 0u;
+    if (asPacket && sc.shadowPackets == 2u) {   // per wavefront: are these 64 rays one bundle?
+      auto first = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+      const float rx = first(ray.o.x), ry = first(ray.o.y), rz = first(ray.o.z);
+      const float ex = ray.o.x - rx, ey = ray.o.y - ry, ez = ray.o.z - rz;
+      asPacket = __builtin_amdgcn_ballot_w64(ex * ex + ey * ey + ez * ez > sc.shadowSpread * (pl.t * pl.t)) == 0ull;
+    }
+    if (asPacket) {
       int* const row = st.lds - __lane_id();
       const int ign = useIgnore ? ignore : -1;
 #ifndef LT_NO_SHADOW_OCTANTS   // (waves whose shadow rays share their direction signs: slab test without min / max, +1.9 % on the wall)

@@ -77,6 +77,34 @@ def triangle_soup(count=1000000, seed=1, camera=None, bvh=None):
                                 camera or camera_bytes(0.0, 2.5, -50.0), bvh)
 
 
+def wall_and_soup(cells=500, count=500000, seed=1, camera=None, bvh=None):
+    """A mixed scene: the height-field wall over the whole frame with a triangle soup floating in front of its left half --
+    coherent and incoherent shadow rays in one image (the per-wavefront choice of the shadow-ray walk)."""
+    x = np.linspace(-5.0, 5.0, cells + 1)
+    y = np.linspace(-2.5, 7.5, cells + 1)
+    X, Y = np.meshgrid(x, y)
+    Z = 0.35 * np.sin(1.7 * X) * np.sin(1.3 * Y) + 0.08 * np.sin(9.0 * X + 5.0 * Y)
+    dZdx = 0.35 * 1.7 * np.cos(1.7 * X) * np.sin(1.3 * Y) + 0.08 * 9.0 * np.cos(9.0 * X + 5.0 * Y)
+    dZdy = 0.35 * 1.3 * np.sin(1.7 * X) * np.cos(1.3 * Y) + 0.08 * 5.0 * np.cos(9.0 * X + 5.0 * Y)
+    P = np.stack([X, Y, Z], axis=-1)
+    N = np.stack([dZdx, dZdy, -np.ones_like(Z)], axis=-1)
+    N /= np.linalg.norm(N, axis=-1, keepdims=True)
+    wp, wn = _grid_triangles(P, N)
+    rng = np.random.default_rng(seed)
+    c = np.stack([rng.uniform(-5, 0, count), rng.uniform(-2.5, 7.5, count), rng.uniform(-3.5, -0.8, count)], axis=-1)
+    e = rng.normal(0.0, 0.03, (count, 3, 3))
+    sp = (c[:, None, :] + e).astype(np.float32)
+    n = np.cross(sp[:, 1] - sp[:, 0], sp[:, 2] - sp[:, 0])
+    n /= np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-20)
+    n *= np.where(n[:, 2:3] > 0, -1.0, 1.0)
+    sn = np.repeat(n[:, None, :], 3, axis=1).astype(np.float32)
+    lp, ln = _light_quad(-1.5, 1.5, 9.5, -9.0, -6.0)
+    mats = _materials([(0.8, 0.8, 0.8), (0.9, 0.3, 0.25), (0.3, 0.75, 0.35)])
+    mi = np.concatenate([np.zeros(len(wp), np.int32), rng.integers(0, 3, count).astype(np.int32), np.full(2, len(mats) - 1, np.int32)])
+    return build_from_triangles(np.concatenate([wp, sp, lp]), np.concatenate([wn, sn, ln]), mi, mats,
+                                camera or camera_bytes(0.0, 2.5, -50.0), bvh)
+
+
 def blob_in_box(subdiv=5, camera=None, bvh=None):
     """Config 3: a displaced, subdivided sphere (20 * 4^subdiv... here a lat-long sphere of ~70 k triangles at the
     default) inside a 5-wall box with a 2-triangle light."""

@@ -109,7 +109,7 @@ def test_bench_partition_of_the_16_sample_frame_reassembles_exactly(renderer, wa
         d = make_desc(C.PROGRAM_ACCUMULATOR, W, H, 3, wall.camera, frame_first=1, frame_count=16, accumulate=True, accumulate_base=0,
                       tile=plan.desc_tile(r))
         renderer.render_device(d, stack[r].data_ptr(), plan.floats_per_rank * 4, stream)
-        assert renderer.stats()["kernel_launches"] in (1, 5)      # (5: the first call of a geometry times both shadow-ray walks on its first frame, twice each)
+        assert renderer.stats()["kernel_launches"] in (1, 7)      # (7: the first call of a geometry times the three shadow-ray walks on its first frame, twice each)
     image = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0")
     renderer.untile(stack.data_ptr(), plan.floats_per_rank, 8, W, H, 3, plan.tile_w, plan.tile_h, image.data_ptr(), stream)
     torch.cuda.synchronize()
@@ -117,18 +117,19 @@ def test_bench_partition_of_the_16_sample_frame_reassembles_exactly(renderer, wa
 
 
 def test_shadow_ray_walks_agree_on_the_full_frame(renderer, wall, monkeypatch):
-    """The any-hit packet walk and the per-lane walk for shadow rays (the library picks one per scene by timing) give the same
-    4K frame, with a rotated camera too (mixed direction signs inside wavefronts)."""
+    """The any-hit packet walk, the per-lane walk and the per-wavefront choice between them for shadow rays (the library picks
+    one per scene by timing) give the same 4K frame, with a rotated camera too (mixed direction signs inside wavefronts)."""
     for yaw in (0.0, 0.4):
         cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, 3)
         frames = {}
-        for mode in ("0", "1"):
+        monkeypatch.setenv("LT_SHADOW_SPREAD", "0.004")     # (the wall's bundles sit around this spread: both walks occur)
+        for mode in ("0", "1", "2"):
             monkeypatch.setenv("LT_SHADOW_PACKETS", mode)
             out = np.empty((H, W, 3), dtype=np.float32)
             renderer.render(RenderPropertiesHIP(ACC, (W, H, 3), out, wall, pCamera=cam, frameFirst=3, frameCount=2, accumulate=True))
             assert renderer.stats()["shadow_packets"] == int(mode)
             frames[mode] = out
-        assert np.array_equal(frames["0"], frames["1"])
+        assert np.array_equal(frames["0"], frames["1"]) and np.array_equal(frames["0"], frames["2"])
 
 
 def test_running_mean_of_16_frames_equals_folding_single_frames(renderer, wall):

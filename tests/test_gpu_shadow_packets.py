@@ -37,9 +37,11 @@ def scenes():
 
 
 @pytest.mark.parametrize("name,scene", list(scenes()), ids=lambda v: v if isinstance(v, str) else "")
-@pytest.mark.parametrize("forced", ["0", "1"], ids=["per-lane", "packets"])
+@pytest.mark.parametrize("forced", ["0", "1", "2"], ids=["per-lane", "packets", "per-wavefront"])
 def test_both_walks_match_the_oracle(renderer, monkeypatch, forced, name, scene):
     monkeypatch.setenv("LT_SHADOW_PACKETS", forced)
+    if forced == "2":
+        monkeypatch.setenv("LT_SHADOW_SPREAD", "0.05" if name in ("soup", "blob") else "0.02")   # (so that both walks occur in these small images)
     cam = sc.camera_with_frame(scene.camera, 3)
     for prog, W, H, kw in (("accumulator", 96, 64, {}), ("accumulator", 33, 17, {"kernelMode": KERNEL_MODE_TILE}),
                            ("global_illumination", 48, 40, {"giMaxDepth": 5}), ("basic_lighting", 24, 16, {}),
@@ -67,9 +69,9 @@ def test_the_walk_is_timed_once_per_scene_program_and_image_geometry(monkeypatch
         return out, r.stats()
 
     out, st = once(PATHS["accumulator"])
-    # the launch's first frame runs four times (packets, per lane, packets, per lane: each walk keeps its faster run), then the
-    # launch itself with the winner
-    assert st["kernel_launches"] == 5 and st["shadow_packets"] in (0, 1)
+    # the launch's first frame runs six times (packets, per lane, chosen per wavefront, twice: each walk keeps its faster run),
+    # then the launch itself with the winner
+    assert st["kernel_launches"] == 7 and st["shadow_packets"] in (0, 1, 2)
     assert np.array_equal(out, want)
     chosen = st["shadow_packets"]
     out, st = once(PATHS["accumulator"])
@@ -80,17 +82,17 @@ def test_the_walk_is_timed_once_per_scene_program_and_image_geometry(monkeypatch
     W, H = 200, 120                                                               # another image geometry: timed again, once
     want = po.render(scene, sc.camera_with_frame(scene.camera, 1), W, H, po.ACCUMULATOR)
     out, st = once(PATHS["accumulator"])
-    assert st["kernel_launches"] == 5 and np.array_equal(out, want)
+    assert st["kernel_launches"] == 7 and np.array_equal(out, want)
     out, st = once(PATHS["accumulator"])
     assert st["kernel_launches"] == 1 and np.array_equal(out, want)
     out, st = once("resources/kernels/opencl/basic.cl")
     assert st["kernel_launches"] == 1 and st["shadow_packets"] == 0               # no shadow rays: nothing to time
     out, st = once(PATHS["basic_lighting"])
-    assert st["kernel_launches"] == 5                                             # its own decision
+    assert st["kernel_launches"] == 7                                             # its own decision
     r.set_scene(synth.heightfield_wall(32).validate())                            # a new scene forgets the decisions
     scene = synth.heightfield_wall(32).validate()
     out, st = once(PATHS["accumulator"], frameFirst=1, frameCount=4, accumulate=True)
-    assert st["kernel_launches"] == 5                                             # timed on the first frame of the fused launch
+    assert st["kernel_launches"] == 7                                             # timed on the first frame of the fused launch
     out2, st = once(PATHS["accumulator"], frameFirst=1, frameCount=4, accumulate=True)
     assert st["kernel_launches"] == 1 and np.array_equal(out, out2)
     r.close()
