@@ -43,7 +43,8 @@ class Stats(ctypes.Structure):
                 ("tri_tests", ctypes.c_uint64), ("pixels", ctypes.c_uint64), ("frames", ctypes.c_uint32),
                 ("kernel_launches", ctypes.c_uint32), ("kernel_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
                 ("render_ms", ctypes.c_float), ("shadow_packets", ctypes.c_int32),
-                ("scene_uploads", ctypes.c_uint32), ("scene_reused", ctypes.c_uint32)]
+                ("scene_uploads", ctypes.c_uint32), ("scene_reused", ctypes.c_uint32),
+                ("own_tree_height", ctypes.c_int32), ("own_tree_ms", ctypes.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -1,6 +1,7 @@
 // lt_capi.hip -- liblenstrace-hip.so: the C ABI of include/lenstrace_hip.h over hand-written gfx950 kernels.
 // Host side of what the reference does in RendererOpenCL::render() (src/opencl/renderer_opencl.cpp:56-153).
 #include "lt_kernel.hpp"
+#include "lt_retree.hpp"
 
 #include "../../include/lenstrace_hip.h"
 
@@ -100,6 +101,10 @@ struct lt_hip_context {
   std::string err;
   hipStream_t stream = nullptr;      // own stream for lt_hip_render
   void *d_nodes = nullptr, *d_pairs = nullptr, *d_tris = nullptr, *d_prims = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+  void *d_nodes2 = nullptr, *d_pairs2 = nullptr;   // the backend's own tree over the scene's leaves (lt_retree.hpp), or null
+  void* d_rank8 = nullptr;                         // with it: the reference's leaf order per direction-sign octant (SceneDev::rank8)
+  int height2 = 0;                                 // its height
+  float retree_ms = 0.0f;                          // host time of its build
   uint32_t n_nodes = 0, n_prims = 0, n_mats = 0;
   int bvh_height = 0;
   bool has_scene = false;
@@ -186,7 +191,7 @@ extern "C" int lt_hip_create(int device_index, lt_hip_context** out_ctx) {
 }
 
 static void free_scene(lt_hip_context* ctx) {
-  for (void** p : {&ctx->d_nodes, &ctx->d_pairs, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights}) {
+  for (void** p : {&ctx->d_nodes, &ctx->d_pairs, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights, &ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_rank8}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -457,6 +462,33 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
   hipLaunchKernelGGL(lt_pair_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes,
                      (float4*)ctx->d_pairs, n_nodes);
   LT_HIP_CHECK(ctx, hipGetLastError());
+  // The backend's own hierarchy over the same leaves (lt_retree.hpp says why the pixels cannot change), for every finite ray of
+  // the non-counting kernels.  LT_RETREE=0 keeps every walk on the caller's tree.
+  ctx->height2 = 0;
+  ctx->retree_ms = 0.0f;
+  {
+    const char* re = getenv("LT_RETREE");
+    std::vector<lt_retree::Node> own;
+    const auto t0 = std::chrono::steady_clock::now();
+    const char* sl = getenv("LT_RETREE_SLACK");
+    const int h2 = (re && atoi(re) == 0) ? -1 : lt_retree::build(nodes, n_nodes, kLdsStack, sl ? atoi(sl) : 0, own);
+    if (h2 >= 0) {
+      ctx->retree_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      const uint32_t n2 = (uint32_t)own.size();
+      LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_nodes2, (size_t)n2 * 32));
+      LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pairs2, (size_t)n2 * 64));
+      LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_nodes2, own.data(), (size_t)n2 * 32, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(lt_pair_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2,
+                         (float4*)ctx->d_pairs2, n2);
+      LT_HIP_CHECK(ctx, hipGetLastError());
+      ctx->height2 = h2;
+      std::vector<uint32_t> rank8;
+      lt_retree::reference_order(nodes, n_prims, rank8);
+      LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_rank8, rank8.size() * sizeof(uint32_t)));
+      LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_rank8, rank8.data(), rank8.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      ctx->retree_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  }
   LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->n_nodes = n_nodes;
   ctx->n_prims = n_prims;
@@ -842,6 +874,9 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   SceneDev sc;
   sc.nodes = (const float4*)ctx->d_nodes;
   sc.pairs = (const float4*)ctx->d_pairs;
+  sc.ownNodes = ctx->d_nodes2 ? (const float4*)ctx->d_nodes2 : sc.nodes;
+  sc.ownPairs = ctx->d_pairs2 ? (const float4*)ctx->d_pairs2 : sc.pairs;
+  sc.rank8 = (const uint32_t*)ctx->d_rank8;
   sc.tris = (const float4*)ctx->d_tris;
   sc.prims = (const float*)ctx->d_prims;
   sc.mats = (const Material*)ctx->d_mats;
@@ -947,7 +982,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       const dim3 grid(persistent ? (uint32_t)std::min<uint64_t>(nblocks * nf, resident) : (uint32_t)nblocks);
       uint32_t* queues = persistent ? ctx->d_queues + (size_t)launchIndex * 8 * kQueueStride : nullptr;
       // LDS stack rows: a lane never holds more entries than a node has interior ancestors (= bvh_height, validate_scene)
-      uint32_t lds = (uint32_t)std::max(1, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
+      uint32_t lds = (uint32_t)std::max(1, std::min(std::max(ctx->bvh_height, ctx->height2), kLdsStack)) * kBlock * sizeof(int);
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
       if (giWavefront) {
         SceneDev scGi = sc;
@@ -1130,5 +1165,7 @@ extern "C" int lt_hip_get_stats(lt_hip_context* ctx, lt_hip_stats* out) {
   *out = ctx->last;
   out->scene_uploads = ctx->scene_uploads;
   out->scene_reused = ctx->scene_reused;
+  out->own_tree_height = ctx->d_nodes2 ? ctx->height2 : -1;
+  out->own_tree_ms = ctx->retree_ms;
   return LT_OK;
 }

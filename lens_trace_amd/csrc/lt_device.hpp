@@ -59,6 +59,15 @@ struct Lights { uint32_t count; uint32_t primitives[64]; };                     
 struct SceneDev {
   const float4* nodes;
   const float4* pairs;      // per interior node index: the records of its two children side by side (64 B; lt_pair_kernel)
+  // The backend's own tree over the caller's leaves (lt_retree.hpp: same leaves, same boxes, binned-SAH hierarchy, same two
+  // layouts), walked by every finite ray of the non-counting kernels; == nodes / pairs when the scene has none.
+  const float4* ownNodes;
+  const float4* ownPairs;
+  // With it, for the closest-hit walks: rank8[8 * primitive + octant] = position of the primitive's leaf in the REFERENCE's
+  // depth-first order for rays of that direction-sign octant.  intersectTriangle keeps the first of two hits with equal t
+  // (`t < payload.t`, acc.cl:104); a walk that meets the leaves in another order keeps the one with the lower rank.  Null
+  // when the walks follow the caller's tree in the reference's order themselves.
+  const uint32_t* rank8;
   const float4* tris;
   const float* prims;       // 19 floats per primitive
   const Material* mats;
@@ -214,8 +223,10 @@ __device__ inline float random_(float uvx, float uvy, float seed) {
 // ---------------------------------------------------------------- traversal
 // acc.cl:72-111 on the re-tiled triangle.  PROGRAM picks the epsilon flavour: basic.cl:78 compares in
 // float against 1e-7f, basic_lighting.cl:4 in double against 1e-7, the others in double against 1e-4.
+// (rank8 / octant / prim: the order table of SceneDev::rank8 for walks over the backend's own tree; null = reference order)
 template <int PROGRAM>
-__device__ __forceinline__ bool intersect_triangle_data(const float4 t0, const float4 t1, const float4 t2, const Ray& ray, Hit& pl, bool fastRcp = false) {
+__device__ __forceinline__ bool intersect_triangle_data(const float4 t0, const float4 t1, const float4 t2, const Ray& ray, Hit& pl, bool fastRcp = false,
+                                                        const uint32_t* rank8 = nullptr, uint32_t octant = 0u, int prim = 0) {
   V4 A = mk4(t0.x, t0.y, t0.z, 1.0f);
   V4 v0v1 = mk4(t0.w, t1.x, t1.y, 0.0f);
   V4 v0v2 = mk4(t1.z, t1.w, t2.x, 0.0f);
@@ -240,7 +251,10 @@ __device__ __forceinline__ bool intersect_triangle_data(const float4 t0, const f
   float v = dot4(ray.d, qvec) * invDet;
   if (v < 0.0f || u + v > 1.0f) return false;
   float tt = dot4(v0v2, qvec) * invDet;
-  if (tt < pl.t) {   // no t > 0 test in the reference
+  bool take = tt < pl.t;   // no t > 0 test in the reference
+  if (tt == pl.t && rank8 != nullptr && pl.hitType == 1)   // (rare: the same t, bit for bit, from two triangles)
+    take = rank8[8 * (size_t)prim + octant] < rank8[8 * (size_t)pl.prim + octant];
+  if (take) {
     pl.t = tt; pl.u = u; pl.v = v;
     return true;
   }
@@ -248,9 +262,10 @@ __device__ __forceinline__ bool intersect_triangle_data(const float4 t0, const f
 }
 
 template <int PROGRAM>
-__device__ __forceinline__ bool intersect_triangle(const float4* __restrict__ tris, int prim, const Ray& ray, Hit& pl, bool fastRcp = false) {
+__device__ __forceinline__ bool intersect_triangle(const float4* __restrict__ tris, int prim, const Ray& ray, Hit& pl, bool fastRcp = false,
+                                                   const uint32_t* rank8 = nullptr, uint32_t octant = 0u) {
   const float4* t = tris + 3 * (size_t)prim;
-  return intersect_triangle_data<PROGRAM>(t[0], t[1], t[2], ray, pl, fastRcp);
+  return intersect_triangle_data<PROGRAM>(t[0], t[1], t[2], ray, pl, fastRcp, rank8, octant, prim);
 }
 template <int PROGRAM>
 __device__ __forceinline__ bool intersect_triangle_lds(uint32_t ldsTris, int prim, const Ray& ray, Hit& pl, bool fastRcp = false) {
@@ -265,7 +280,8 @@ __device__ __forceinline__ bool intersect_triangle_lds(uint32_t ldsTris, int pri
 // whatever their registers hold and are masked out of every decision (no float exception traps on this path).
 template <int PROGRAM>
 __device__ __forceinline__ bool intersect_triangle_packet(const float4 t0, const float4 t1, const float4 t2, const Ray& ray, Hit& pl,
-                                                          bool active, int prim, bool fastRcp = false) {
+                                                          bool active, int prim, bool fastRcp = false, const uint32_t* rank8 = nullptr,
+                                                          uint32_t octant = 0u) {
   const V4 A = mk4(t0.x, t0.y, t0.z, 1.0f);
   const V4 v0v1 = mk4(t0.w, t1.x, t1.y, 0.0f);
   const V4 v0v2 = mk4(t1.z, t1.w, t2.x, 0.0f);
@@ -283,7 +299,11 @@ __device__ __forceinline__ bool intersect_triangle_packet(const float4 t0, const
   const float v = dot4(ray.d, qvec) * invDet;
   ok = ok && !(v < 0.0f || u + v > 1.0f);
   const float tt = dot4(v0v2, qvec) * invDet;
-  ok = ok && (tt < pl.t);
+  bool take = tt < pl.t;
+  if (rank8 != nullptr && __builtin_amdgcn_ballot_w64(ok && tt == pl.t && pl.hitType == 1) != 0ull) {   // (rare)
+    if (ok && tt == pl.t && pl.hitType == 1) take = rank8[8 * (size_t)prim + octant] < rank8[8 * (size_t)pl.prim + octant];
+  }
+  ok = ok && take;
   pl.t = ok ? tt : pl.t;
   pl.u = ok ? u : pl.u;
   pl.v = ok ? v : pl.v;
@@ -439,8 +459,11 @@ __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float 
 template <int PROGRAM, bool DEEP, bool STATS, bool FINITE, bool ANYHIT, bool LDSSCENE = false>
 __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool useIgnore, int ignore,
                                      Hit& pl, Stack<DEEP>& st, Counters& c) {
+  // finite rays of the non-counting kernels walk the backend's own tree (lt_retree.hpp; == the caller's when there is none)
+  constexpr bool OWN = FINITE && !STATS && !LDSSCENE;
   const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
   const uint32_t negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);   // dirIsNeg[axis] = bit `axis` (axis <= 2: set_scene)
+  const uint32_t* const rank8 = (OWN && !ANYHIT) ? sc.rank8 : nullptr;
   const int ign = useIgnore ? ignore : -1;   // leaf offsets are >= 0
   int cur = 0;
   typename Stack<DEEP>::Pos sp = st.bottom();   // where the next entry goes
@@ -455,7 +478,7 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
       const LdsF4 n = (LdsF4)(size_t)(sc.ldsNodes + ((uint32_t)cur << 5));
       a = ld_lds(n); b = ld_lds(n + 1);
     } else {
-      const float4* n = (const float4*)((const char*)sc.nodes + ((uint32_t)cur << 5));
+      const float4* n = (const float4*)((const char*)(OWN ? sc.ownNodes : sc.nodes) + ((uint32_t)cur << 5));
       a = n[0]; b = n[1];
     }
     // the entry below the top is read now, beside the node fetch, whether or not this node turns out to need it
@@ -471,7 +494,8 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
     if (pend >= 0) {   // the leaf noted in the previous iteration
       LT_WAVE_COUNT(wTri);
       if (STATS) c.tris += pendCount;    // the reference *calls* intersectTriangle primitiveCount times
-      if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl, sc.fastRcp != 0u) : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, sc.fastRcp != 0u)) {
+      if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl, sc.fastRcp != 0u)
+                   : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, sc.fastRcp != 0u, rank8, negBits)) {
         pl.prim = pend;
         pl.hitType = 1;
         if (ANYHIT) return;
@@ -495,7 +519,8 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
   if (pend >= 0) {
     LT_WAVE_COUNT(wTri);
     if (STATS) c.tris += pendCount;
-    if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl, sc.fastRcp != 0u) : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, sc.fastRcp != 0u)) {
+    if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl, sc.fastRcp != 0u)
+                 : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, sc.fastRcp != 0u, rank8, negBits)) {
       pl.prim = pend;
       pl.hitType = 1;
     }
@@ -609,8 +634,8 @@ template <int PROGRAM, int NEG>
 __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, Hit& pl, int* ldsWave) {
   using u64 = unsigned long long;
   constexpr uint32_t kLeafTag = 0x80000000u;
-  const ConstF4 nodes = (ConstF4)(unsigned long long)sc.nodes;
-  const ConstF4 pairs = (ConstF4)(unsigned long long)sc.pairs;
+  const ConstF4 nodes = (ConstF4)(unsigned long long)sc.ownNodes;
+  const ConstF4 pairs = (ConstF4)(unsigned long long)sc.ownPairs;
   const ConstF4 tris = (ConstF4)(unsigned long long)sc.tris;
   const int lane = (int)__lane_id();
   constexpr uint32_t negBitsU = (uint32_t)NEG;   // the direction signs the whole wave shares, a compile-time constant here
@@ -618,10 +643,10 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
     const ConstF4 t = tris + 3 * (size_t)off;
     const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
 #ifndef LT_BRANCHY_PACKET_LEAF
-    intersect_triangle_packet<PROGRAM>(t0, t1, t2, ray, pl, ((m >> lane) & 1ull) != 0ull, (int)off, sc.fastRcp != 0u);
+    intersect_triangle_packet<PROGRAM>(t0, t1, t2, ray, pl, ((m >> lane) & 1ull) != 0ull, (int)off, sc.fastRcp != 0u, sc.rank8, negBitsU);
 #else
     if ((m >> lane) & 1ull) {
-      if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl, sc.fastRcp != 0u)) {
+      if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl, sc.fastRcp != 0u, sc.rank8, negBitsU, (int)off)) {
         pl.prim = (int)off;
         pl.hitType = 1;
       }
@@ -644,7 +669,7 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
     const float eps = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
                       : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
     const uint32_t ldsBase = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)ldsWave;
-    packet_closest_walk<NEG>((const void*)sc.pairs, (const void*)sc.tris, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y, ray.d.z,
+    packet_closest_walk<NEG>((const void*)sc.ownPairs, (const void*)sc.tris, (const void*)sc.rank8, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y, ray.d.z,
                              ray.d.w, eps, sc.fastRcp, ldsBase, cur, mask, pl.t, pl.u, pl.v, pl.prim, pl.hitType);
     return;
   }
@@ -721,8 +746,8 @@ template <int PROGRAM, int NEG = -1>   // NEG >= 0: all rays of the wave share t
 __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl,
                                                     int* ldsWave) {
   using u64 = unsigned long long;
-  const ConstF4 nodes = (ConstF4)(unsigned long long)sc.nodes;
-  const ConstF4 pairs = (ConstF4)(unsigned long long)sc.pairs;
+  const ConstF4 nodes = (ConstF4)(unsigned long long)sc.ownNodes;
+  const ConstF4 pairs = (ConstF4)(unsigned long long)sc.ownPairs;
   const ConstF4 tris = (ConstF4)(unsigned long long)sc.tris;
   const int lane = (int)__lane_id();
   const float tmax = pl.t;
@@ -752,7 +777,7 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
       const float epsBits = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
                             : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
       const uint32_t ldsBase = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)ldsWave;
-      openMask = packet_anyhit_walk<NEG>((const void*)sc.pairs, (const void*)sc.tris, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y,
+      openMask = packet_anyhit_walk<NEG>((const void*)sc.ownPairs, (const void*)sc.tris, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y,
                                          ray.d.z, ray.d.w, tmax, ign, epsBits, sc.fastRcp, ldsBase, mask, openMask);
       return;
     }

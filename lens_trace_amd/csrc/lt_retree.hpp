@@ -1,0 +1,258 @@
+// The backend's own traversal tree over the reference's leaves, built on the host at lt_hip_set_scene (host code only).
+//
+// Why a different tree gives the same pixels.  The reference's traversal (acc.cl:132-217) reaches a leaf iff the ray passes the
+// slab test (acc.cl:113-130) of every ancestor's box and of the leaf's own box, and it never clips against the closest hit.
+// For a ray whose origin and inverse direction are finite the slab test is monotonic in the box: (bound - o) * inv is a
+// monotonic function of `bound` in float arithmetic (rounding is monotonic), so enlarging a box can only lower the largest
+// entry distance and raise the smallest exit distance -- a ray that passes the test of a box passes the test of every box that
+// encloses it.  When every node's box encloses its children's boxes (checked here, node by node, on the caller's buffer), "passes
+// every ancestor and the leaf" is therefore the same set of leaves as "passes the leaf's own box", whatever hierarchy is used
+// to enumerate candidates -- provided that hierarchy's boxes enclose their leaves too (they are unions of them) and the leaf's
+// own box, bit for bit the reference's, is still tested.  The triangle tests that follow are the reference's; which of them run
+// is the same set; what differs is the ORDER, which matters in one place only: two triangles whose accepted hits have exactly
+// equal t (intersectTriangle accepts t < payload.t, so the first one tested stays).  Shadow rays do not care (their callers
+// read hitType only); closest-hit walks resolve such ties with the reference's order (lt_device.hpp, `rank8`).
+// Rays with a non-finite component, the counting kernels (whose per-ray node counts are the reference's) and scenes whose
+// boxes do not nest keep walking the caller's tree.
+//
+// The tree: binned surface-area heuristic (32 bins per axis over the centroid bounds, all three axes), one reference leaf per
+// leaf, the reference's 32-byte node layout and pre-order numbering (left child = i + 1), so that every walk and the
+// child-pair kernel read it as they read the caller's buffer.  Without clipping, the expected number of nodes a ray visits is
+// exactly the surface-area sum the heuristic minimises.  Height is bounded (the walks' LDS stacks are as deep as the tree).
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+namespace lt_retree {
+
+struct Node {   // LinearBVHNode (include/lens_trace/acceleration_structure_explicit.h:20-32)
+  float lo[3], hi[3];
+  int32_t off;
+  uint16_t cnt;
+  uint8_t axis, pad;
+};
+static_assert(sizeof(Node) == 32, "LinearBVHNode is 32 bytes");
+
+constexpr int kBins = 32;
+
+inline int ceil_log2(uint32_t x) {
+  int l = 0;
+  while ((1ull << l) < x) l++;
+  return l;
+}
+
+// Reachable leaves of the caller's tree in its own pre-order, or false when the boxes do not nest (or hold a NaN).
+inline bool collect_leaves(const Node* nd, uint32_t n_nodes, std::vector<uint32_t>& leaves) {
+  leaves.clear();
+  std::vector<uint32_t> stack{0u};
+  while (!stack.empty()) {
+    const uint32_t i = stack.back();
+    stack.pop_back();
+    const Node& p = nd[i];
+    if (p.cnt != 0) { leaves.push_back(i); continue; }
+    const uint32_t kids[2] = {i + 1, (uint32_t)p.off};
+    for (uint32_t k : kids) {
+      const Node& c = nd[k];
+      for (int a = 0; a < 3; a++)
+        if (!(c.lo[a] >= p.lo[a] && c.hi[a] <= p.hi[a] && c.lo[a] <= c.hi[a])) return false;
+    }
+    stack.push_back(kids[1]);
+    stack.push_back(kids[0]);
+    if (leaves.size() + stack.size() > n_nodes) return false;   // (a shared child: not a tree)
+  }
+  return true;
+}
+
+struct Range { uint32_t start, end, node; int depth; };
+
+// Builds the subtree of the leaves order[start, end) at out[node ...] (a pre-order subtree of k leaves owns out[node, node + 2k - 1)
+// and order[start, end): nothing is shared between subtrees); returns the deepest level reached.  With `deferred`, subtrees of at
+// most `deferCount` leaves below the root are not built but listed there, for other threads.
+inline int build_range(const Node* nd, const float* centroid, std::vector<uint32_t>& order, Node* out, Range root, int heightLimit,
+                       std::vector<Range>* deferred = nullptr, uint32_t deferCount = 0) {
+  int height = root.depth;
+  std::vector<Range> work{root};
+  struct Bin { float lo[3], hi[3]; uint32_t count; };
+  while (!work.empty()) {
+    const Range r = work.back();
+    work.pop_back();
+    if (deferred && r.node != root.node && r.end - r.start <= deferCount) { deferred->push_back(r); continue; }
+    Node& node = out[r.node];
+    height = std::max(height, r.depth);
+    const uint32_t count = r.end - r.start;
+    if (count == 1) {
+      node = nd[order[r.start]];   // the reference's leaf, box and offset bit for bit
+      continue;
+    }
+    float cmin[3], cmax[3];
+    for (int a = 0; a < 3; a++) {
+      node.lo[a] = cmin[a] = std::numeric_limits<float>::max();
+      node.hi[a] = cmax[a] = -std::numeric_limits<float>::max();
+    }
+    for (uint32_t i = r.start; i < r.end; i++) {
+      const Node& p = nd[order[i]];
+      const float* c = centroid + 3 * (size_t)order[i];
+      for (int a = 0; a < 3; a++) {
+        node.lo[a] = std::min(node.lo[a], p.lo[a]);
+        node.hi[a] = std::max(node.hi[a], p.hi[a]);
+        cmin[a] = std::min(cmin[a], c[a]);
+        cmax[a] = std::max(cmax[a], c[a]);
+      }
+    }
+    const float d[3] = {cmax[0] - cmin[0], cmax[1] - cmin[1], cmax[2] - cmin[2]};
+    int dim = (d[0] > d[1] && d[0] > d[2]) ? 0 : (d[1] > d[2] ? 1 : 2);
+    uint32_t mid = r.start + count / 2;
+    bool split = false;
+    // a child of k leaves needs ceil(log2 k) more levels at least: both children must fit under the height limit
+    const int room = heightLimit - r.depth - 1;
+    const uint32_t maxChild = room >= 31 ? count : (uint32_t)std::min<uint64_t>(count, 1ull << std::max(0, room));
+    if (count > 2 && maxChild >= (count + 1) / 2) {
+      Bin bins[3][kBins];
+      for (int a = 0; a < 3; a++)
+        for (Bin& b : bins[a]) {
+          for (int k = 0; k < 3; k++) { b.lo[k] = std::numeric_limits<float>::max(); b.hi[k] = -std::numeric_limits<float>::max(); }
+          b.count = 0;
+        }
+      float scale[3];
+      for (int a = 0; a < 3; a++) scale[a] = d[a] > 0.0f ? (float)kBins / d[a] : 0.0f;
+      for (uint32_t i = r.start; i < r.end; i++) {
+        const Node& p = nd[order[i]];
+        const float* c = centroid + 3 * (size_t)order[i];
+        for (int a = 0; a < 3; a++) {
+          if (!(d[a] > 0.0f)) continue;
+          Bin& b = bins[a][std::min(kBins - 1, std::max(0, (int)((c[a] - cmin[a]) * scale[a])))];
+          b.count++;
+          for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], p.lo[k]); b.hi[k] = std::max(b.hi[k], p.hi[k]); }
+        }
+      }
+      auto half_area = [](const float* lo, const float* hi) {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+      };
+      float bestCost = std::numeric_limits<float>::max();
+      int bestDim = -1, bestBin = -1;
+      for (int a = 0; a < 3; a++) {
+        if (!(d[a] > 0.0f)) continue;
+        float rightArea[kBins];
+        uint32_t rightCount[kBins];
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::max(); hi[k] = -std::numeric_limits<float>::max(); }
+        uint32_t c = 0;
+        for (int b = kBins - 1; b >= 0; b--) {
+          const Bin& bn = bins[a][b];
+          if (bn.count) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], bn.lo[k]); hi[k] = std::max(hi[k], bn.hi[k]); }
+          c += bn.count;
+          rightCount[b] = c;
+          rightArea[b] = c ? half_area(lo, hi) : 0.0f;
+        }
+        for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::max(); hi[k] = -std::numeric_limits<float>::max(); }
+        c = 0;
+        for (int b = 0; b + 1 < kBins; b++) {   // split after bin b
+          const Bin& bn = bins[a][b];
+          if (bn.count) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], bn.lo[k]); hi[k] = std::max(hi[k], bn.hi[k]); }
+          c += bn.count;
+          const uint32_t rc = rightCount[b + 1];
+          if (c == 0 || rc == 0 || c > maxChild || rc > maxChild) continue;
+          const float cost = half_area(lo, hi) * (float)c + rightArea[b + 1] * (float)rc;
+          if (cost < bestCost) { bestCost = cost; bestDim = a; bestBin = b; }
+        }
+      }
+      if (bestDim >= 0) {
+        const float sc = scale[bestDim], c0 = cmin[bestDim];
+        auto it = std::stable_partition(order.begin() + r.start, order.begin() + r.end, [&](uint32_t i) {
+          return std::min(kBins - 1, std::max(0, (int)((centroid[3 * (size_t)i + bestDim] - c0) * sc))) <= bestBin;
+        });
+        mid = (uint32_t)(it - order.begin());
+        dim = bestDim;
+        split = true;
+      }
+    }
+    if (!split && d[dim] > 0.0f) {   // median of the largest centroid extent (no plane separates the centroids, or no room under the height limit)
+      std::nth_element(order.begin() + r.start, order.begin() + mid, order.begin() + r.end, [&](uint32_t a, uint32_t b) {
+        const float ca = centroid[3 * (size_t)a + dim], cb = centroid[3 * (size_t)b + dim];
+        return ca < cb || (ca == cb && a < b);
+      });
+    }
+    node.axis = (uint8_t)dim;
+    node.cnt = 0;
+    node.pad = 0;
+    const uint32_t leftCount = mid - r.start;
+    node.off = (int32_t)(r.node + 2 * leftCount);   // r.node + 1 + (2 * leftCount - 1)
+    work.push_back({mid, r.end, (uint32_t)node.off, r.depth + 1});
+    work.push_back({r.start, mid, r.node + 1, r.depth + 1});
+  }
+  return height;
+}
+
+// out: 2 * leaves - 1 nodes.  Returns the height (interior ancestors of the deepest leaf), or -1 when no tree is built (boxes do
+// not nest, fewer than two leaves, or the tree cannot fit under maxHeight).
+inline int build(const void* nodes, uint32_t n_nodes, int maxHeight, int slack, std::vector<Node>& out, int threads = 0) {
+  const Node* nd = reinterpret_cast<const Node*>(nodes);
+  std::vector<uint32_t> order;
+  if (!collect_leaves(nd, n_nodes, order) || order.size() < 2) return -1;
+  const uint32_t n = (uint32_t)order.size();
+  if ((uint64_t)n * 2 - 1 > 0x03ffffffull) return -1;   // (64-byte pair records behind 32-bit byte offsets)
+  const int heightLimit = std::min(maxHeight, ceil_log2(n) + slack);
+  if (heightLimit < ceil_log2(n)) return -1;
+  std::vector<float> centroid(3 * (size_t)n_nodes);
+  for (uint32_t i : order)
+    for (int a = 0; a < 3; a++) centroid[3 * (size_t)i + a] = 0.5f * nd[i].lo[a] + 0.5f * nd[i].hi[a];
+  out.assign(2 * (size_t)n - 1, Node{});
+  // the top of the tree on this thread until there are enough independent subtrees for the others (a pre-order subtree of k
+  // leaves owns out[node, node + 2k - 1) and order[start, end): nothing is shared)
+  if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (n < 50000u) threads = 1;
+  if (threads == 1) return build_range(nd, centroid.data(), order, out.data(), Range{0, n, 0, 0}, heightLimit);
+  // the top of the tree on this thread, the subtrees below it on all of them
+  std::vector<Range> parts;
+  int height = build_range(nd, centroid.data(), order, out.data(), Range{0, n, 0, 0}, heightLimit, &parts, n / (8u * (uint32_t)threads) + 1u);
+  std::sort(parts.begin(), parts.end(), [](const Range& a, const Range& b) { return a.end - a.start > b.end - b.start; });
+  std::atomic<size_t> next{0};
+  std::vector<int> heights((size_t)threads, 0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; t++)
+    pool.emplace_back([&, t]() {
+      for (size_t k = next.fetch_add(1); k < parts.size(); k = next.fetch_add(1))
+        heights[(size_t)t] = std::max(heights[(size_t)t], build_range(nd, centroid.data(), order, out.data(), parts[k], heightLimit));
+    });
+  for (std::thread& th : pool) th.join();
+  for (int h : heights) height = std::max(height, h);
+  return height;
+}
+
+// rank8[8 * primitive + octant]: position of the primitive's (first) leaf in the caller's tree walked depth-first, near child
+// first, by a ray whose direction signs are `octant` (bit a = component a negative: the reference's dirIsNeg[node->axis],
+// acc.cl:150-160).  0xffffffff for primitives no leaf refers to.
+inline void reference_order(const void* nodes, uint32_t n_prims, std::vector<uint32_t>& rank8) {
+  const Node* nd = reinterpret_cast<const Node*>(nodes);
+  rank8.assign(8 * (size_t)n_prims, 0xffffffffu);
+  auto one = [&](uint32_t octant) {
+    std::vector<uint32_t> stack{0u};
+    uint32_t next = 0;
+    while (!stack.empty()) {
+      const uint32_t i = stack.back();
+      stack.pop_back();
+      const Node& p = nd[i];
+      if (p.cnt != 0) {
+        uint32_t& r = rank8[8 * (size_t)(uint32_t)p.off + octant];
+        if (r == 0xffffffffu) r = next;
+        next++;
+        continue;
+      }
+      const bool neg = ((octant >> p.axis) & 1u) != 0u;
+      stack.push_back(neg ? i + 1 : (uint32_t)p.off);   // far child, visited second
+      stack.push_back(neg ? (uint32_t)p.off : i + 1);   // near child
+    }
+  };
+  std::vector<std::thread> pool;
+  for (uint32_t o = 0; o < 8; o++) pool.emplace_back(one, o);   // (eight writers, eight disjoint sets of words)
+  for (std::thread& th : pool) th.join();
+}
+
+}  // namespace lt_retree

@@ -392,7 +392,7 @@ __device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, const vo
   "s_mov_b32 %[cur], -1\n"                                                                                                      \
   "s_branch .Lleaf%=\n"
 
-#define LT_ASM_CLOSEST_WALK(BOXES, NEGBITS)                                                                                     \
+#define LT_ASM_CLOSEST_WALK(BOXES, NEGBITS, ROFF)                                                                                    \
   "s_mov_b64 " LT_R_EXEC ", exec\n"                                                                                             \
   ".Ltop%=:\n"                                                                                                                  \
   LT_ASM_LOAD_NODE                                                                                                              \
@@ -421,7 +421,27 @@ __device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, const vo
   LT_ASM_LEAF_PROLOGUE                                                                                                          \
   LT_ASM_TRI_PART1                                                                                                              \
   LT_ASM_TRI_PART2                                                                                                              \
-  "v_cmpx_lt_f32_e64 " LT_R_HML ", %[t3], %[pt]\n"  /* t < payload.t (no t > 0 test in the reference) */                        \
+  "v_cmp_eq_f32_e64 " LT_R_HMR ", %[t3], %[pt]\n"   /* the same t again, bit for bit? (rare) */                                 \
+  "v_cmp_lt_f32_e64 " LT_R_HML ", %[t3], %[pt]\n"   /* t < payload.t (no t > 0 test in the reference) */                        \
+  "s_cmp_lg_u64 " LT_R_HMR ", 0\n"                                                                                              \
+  "s_cbranch_scc0 .Ltake%=\n"                                                                                                   \
+  /* Two triangles, one t: the reference keeps the one its own depth-first order meets first.  This walk follows the backend's   \
+     tree, so the order comes from the table (SceneDev::rank8: 8 ranks per primitive, one per direction-sign octant). */         \
+  "s_cmp_lg_u64 %[ranks], 0\n"                      /* no table: this IS the reference's order */                               \
+  "s_cbranch_scc0 .Ltake%=\n"                                                                                                   \
+  "s_mov_b64 " LT_R_TMPM ", exec\n"                                                                                             \
+  "s_mov_b64 exec, " LT_R_HMR "\n"                                                                                              \
+  "v_cmpx_eq_u32_e64 " LT_R_HMR ", 1, %[phit]\n"    /* ... against a hit the lane already holds */                              \
+  "v_lshlrev_b32_e32 %[t4], 5, %[pprim]\n"                                                                                      \
+  "global_load_dword %[t5], %[t4], %[ranks] offset:" ROFF "\n"                                                                  \
+  "s_lshl_b32 " LT_R_LEAF ", " LT_R_PRIM ", 5\n"                                                                                \
+  "s_load_dword " LT_R_LEAF ", %[ranks], " LT_R_LEAF " offset:" ROFF "\n"                                                       \
+  "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                                                             \
+  "v_cmpx_gt_u32_e64 " LT_R_HMR ", %[t5], " LT_R_LEAF "\n" /* this triangle's leaf comes first */                               \
+  "s_or_b64 " LT_R_HML ", " LT_R_HML ", exec\n"                                                                                 \
+  "s_mov_b64 exec, " LT_R_TMPM "\n"                                                                                             \
+  ".Ltake%=:\n"                                                                                                                 \
+  "s_and_b64 exec, exec, " LT_R_HML "\n"                                                                                        \
   "v_mov_b32_e32 %[pt], %[t3]\n"                    /* the lanes still in EXEC take the hit */                                  \
   "v_mov_b32_e32 %[pu], %[t1]\n"                                                                                                \
   "v_mov_b32_e32 %[pv], %[t2]\n"                                                                                                \
@@ -434,27 +454,27 @@ __device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, const vo
 // The whole closest-hit walk below the root.  `cur` = the root's reference (index 0 | its split axis << 29), `mask` = the lanes
 // that hit the root's box.
 template <int NEG>
-__device__ __forceinline__ void packet_closest_walk(const void* pairs, const void* tris, float ox, float oy, float oz, float ix, float iy,
+__device__ __forceinline__ void packet_closest_walk(const void* pairs, const void* tris, const void* ranks, float ox, float oy, float oz, float ix, float iy,
                                                     float iz, float dx, float dy, float dz, float dw, float eps, uint32_t fast, uint32_t lds,
                                                     uint32_t cur, lt_u64 mask, float& pt, float& pu, float& pv, int& pprim, int& phit) {
   uint32_t sp = 0u;
   float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
-#define LT_CLOSEST_INSTANCE(BOXES, NEGBITS)                                                                                              \
-  asm volatile(LT_ASM_CLOSEST_WALK(BOXES, NEGBITS)                                                                                       \
+#define LT_CLOSEST_INSTANCE(BOXES, NEGBITS, ROFF)                                                                                            \
+  asm volatile(LT_ASM_CLOSEST_WALK(BOXES, NEGBITS, ROFF)                                                                                     \
                : [cur] "+s"(cur), [mask] "+s"(mask), [sp] "+s"(sp), [pt] "+v"(pt), [pu] "+v"(pu), [pv] "+v"(pv), [pprim] "+v"(pprim),    \
                  [phit] "+v"(phit), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),     \
                  [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9), [t10] "=&v"(t10)                                        \
-               : [pairs] "s"(pairs), [tris] "s"(tris), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), \
+               : [pairs] "s"(pairs), [tris] "s"(tris), [ranks] "s"(ranks), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), \
                  [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [dw] "v"(dw), [eps] "s"(eps), [fast] "s"(fast), [lds] "v"(lds)                  \
                : LT_ASM_CLOBBERS)
-  if constexpr (NEG == 0) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_0, "0");
-  else if constexpr (NEG == 1) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_1, "1");
-  else if constexpr (NEG == 2) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_2, "2");
-  else if constexpr (NEG == 3) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_3, "3");
-  else if constexpr (NEG == 4) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_4, "4");
-  else if constexpr (NEG == 5) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_5, "5");
-  else if constexpr (NEG == 6) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_6, "6");
-  else LT_CLOSEST_INSTANCE(LT_ASM_BOXES_7, "7");
+  if constexpr (NEG == 0) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_0, "0", "0");
+  else if constexpr (NEG == 1) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_1, "1", "4");
+  else if constexpr (NEG == 2) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_2, "2", "8");
+  else if constexpr (NEG == 3) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_3, "3", "12");
+  else if constexpr (NEG == 4) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_4, "4", "16");
+  else if constexpr (NEG == 5) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_5, "5", "20");
+  else if constexpr (NEG == 6) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_6, "6", "24");
+  else LT_CLOSEST_INSTANCE(LT_ASM_BOXES_7, "7", "28");
 #undef LT_CLOSEST_INSTANCE
 }
 
