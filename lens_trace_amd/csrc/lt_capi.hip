@@ -104,7 +104,9 @@ struct lt_hip_context {
   void *d_nodes2 = nullptr, *d_pairs2 = nullptr;   // the backend's own tree over the scene's leaves (lt_retree.hpp), or null
   void* d_rank8 = nullptr;                         // with it: the reference's leaf order per direction-sign octant (SceneDev::rank8)
   int height2 = 0;                                 // its height
+  uint32_t n_nodes2 = 0;
   float retree_ms = 0.0f;                          // host time of its build
+  uint32_t lds_ref_bytes = 0;                      // LDS of a wave whose per-lane stack follows the caller's tree (set per render call)
   uint32_t n_nodes = 0, n_prims = 0, n_mats = 0;
   int bvh_height = 0;
   bool has_scene = false;
@@ -471,7 +473,7 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
     std::vector<lt_retree::Node> own;
     const auto t0 = std::chrono::steady_clock::now();
     const char* sl = getenv("LT_RETREE_SLACK");
-    const int h2 = (re && atoi(re) == 0) ? -1 : lt_retree::build(nodes, n_nodes, kLdsStack, sl ? atoi(sl) : 0, own);
+    const int h2 = (re && atoi(re) == 0) ? -1 : lt_retree::build(nodes, n_nodes, kLdsStack, sl ? atoi(sl) : 2, own);
     if (h2 >= 0) {
       ctx->retree_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
       const uint32_t n2 = (uint32_t)own.size();
@@ -481,6 +483,10 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
       hipLaunchKernelGGL(lt_pair_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2,
                          (float4*)ctx->d_pairs2, n2);
       LT_HIP_CHECK(ctx, hipGetLastError());
+      LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      lt_retree::thread(own);   // (the pair records are made: now the form the stackless per-lane walks read)
+      LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_nodes2, own.data(), (size_t)n2 * 32, hipMemcpyHostToDevice));
+      ctx->n_nodes2 = n2;
       ctx->height2 = h2;
       std::vector<uint32_t> rank8;
       lt_retree::reference_order(nodes, n_prims, rank8);
@@ -614,12 +620,12 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   const uint64_t sceneLdsBytes = (uint64_t)ctx->n_nodes * 32 + (uint64_t)ctx->n_prims * 48;
   const char* le = getenv("LT_GI_LDS_SCENE");
   const bool ldsScene = !CFG::kDeep && sceneLdsBytes <= 16384 && !(le && atoi(le) == 0);
-  gp.ldsRows = lds / (kBlock * sizeof(int));
+  gp.ldsRows = ctx->lds_ref_bytes / (kBlock * sizeof(int));   // (read by the multi-wave workgroups of the LDS-scene launches only)
   for (int d = 0; d < fp.giMaxDepth; d++) {
     if (ldsScene) {
       using CFGL = Config<false, false, CFG::kDevLibm, true>;
       hipLaunchKernelGGL((lt_gi_bounce_kernel<CFGL>), dim3((resident + kLdsSceneWaves - 1) / kLdsSceneWaves), dim3(kBlock * kLdsSceneWaves),
-                         (uint32_t)sceneLdsBytes + kLdsSceneWaves * lds, s, sc, fp, gp, (uint32_t)d);
+                         (uint32_t)sceneLdsBytes + kLdsSceneWaves * ctx->lds_ref_bytes, s, sc, fp, gp, (uint32_t)d);
     } else {
       hipLaunchKernelGGL((lt_gi_bounce_kernel<CFG>), dim3(resident), dim3(kBlock), lds, s, sc, fp, gp, (uint32_t)d);
     }
@@ -877,6 +883,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   sc.ownNodes = ctx->d_nodes2 ? (const float4*)ctx->d_nodes2 : sc.nodes;
   sc.ownPairs = ctx->d_pairs2 ? (const float4*)ctx->d_pairs2 : sc.pairs;
   sc.rank8 = (const uint32_t*)ctx->d_rank8;
+  sc.nOwn = ctx->d_rank8 ? ctx->n_nodes2 : 0u;
   sc.tris = (const float4*)ctx->d_tris;
   sc.prims = (const float*)ctx->d_prims;
   sc.mats = (const Material*)ctx->d_mats;
@@ -982,8 +989,11 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       const dim3 grid(persistent ? (uint32_t)std::min<uint64_t>(nblocks * nf, resident) : (uint32_t)nblocks);
       uint32_t* queues = persistent ? ctx->d_queues + (size_t)launchIndex * 8 * kQueueStride : nullptr;
       // LDS stack rows: a lane never holds more entries than a node has interior ancestors (= bvh_height, validate_scene)
-      uint32_t lds = (uint32_t)std::max(1, std::min(std::max(ctx->bvh_height, ctx->height2), kLdsStack)) * kBlock * sizeof(int);
-      if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)atoi(e) * kBlock * sizeof(int);   // occupancy experiments
+      // The counting kernels (and the LDS-resident small scenes of the GI bounce stage: launch_gi_sample) keep one stack entry
+      // per lane and level of the caller's tree in LDS; the others need the packet walks' two rows only (kPacketRows).
+      ctx->lds_ref_bytes = (uint32_t)std::max(kPacketRows, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
+      uint32_t lds = stats ? ctx->lds_ref_bytes : (uint32_t)kPacketRows * kBlock * sizeof(int);
+      if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)std::max(kPacketRows, atoi(e)) * kBlock * sizeof(int);   // occupancy experiments
       if (giWavefront) {
         SceneDev scGi = sc;
         scGi.shadowPackets = spe ? sc.shadowPackets : 0u;   // the pipeline's bounce stages cast incoherent shadow rays: per lane

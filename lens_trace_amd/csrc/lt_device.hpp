@@ -34,6 +34,8 @@ constexpr int kQueueStride = 64;   // dwords between work counters: one 256-byte
                                    // cache line serialise every wave of the chip on one memory channel, 12 ns per work
                                    // item: 25 ms of a 2-million-item launch, whatever the items cost.  Taking several
                                    // items per atomic on top of the padding does not pay: -1 % at 4, -2.4 % at 8.)
+constexpr int kPacketEntry = 4;    // dwords per entry of a packet walk's wave-uniform stack (node reference + 64-bit lane mask, one spare)
+constexpr int kPacketRows = 2;     // ... which therefore fits 32 entries -- kLdsStack levels -- in two 256-byte rows of the wave's LDS
 constexpr int kMaxStack = 64;      // the reference's nodesToVisit[64] (acc.cl:137)
 constexpr float kFltMax = 3.402823466e+38f;
 
@@ -68,6 +70,9 @@ struct SceneDev {
   // (`t < payload.t`, acc.cl:104); a walk that meets the leaves in another order keeps the one with the lower rank.  Null
   // when the walks follow the caller's tree in the reference's order themselves.
   const uint32_t* rank8;
+  uint32_t nOwn;            // nodes of the own tree, whose interior nodes hold their ESCAPE index where the caller's hold the second
+                            // child (lt_retree.hpp: the node that follows the subtree in pre-order, nOwn at the end): the per-lane
+                            // walks over it need no stack (traverse_own_lane)
   const float4* tris;
   const float* prims;       // 19 floats per primitive
   const Material* mats;
@@ -366,6 +371,21 @@ struct Stack {
   __device__ __forceinline__ void store(Pos p, int v) { if constexpr (DEEP) push(p, v); else *p = v; }
 };
 
+// The reference's own `int nodesToVisit[64]` (acc.cl:137) in private memory, for the walks of the non-counting kernels that must
+// follow the caller's tree in the reference's order: rays with a non-finite component (the image's centre row / column), and
+// every ray of a scene whose boxes do not nest.  Rare, so their stack costs no LDS (the launches of those kernels reserve two
+// rows per wave, for the packet walks).
+struct ScratchStack {
+  int e[kMaxStack];
+  using Pos = int;
+  __device__ __forceinline__ Pos bottom() { return 0; }
+  __device__ __forceinline__ bool above_bottom(Pos p) { return p > 0; }
+  __device__ __forceinline__ Pos below(Pos p) { return p > 0 ? p - 1 : 0; }
+  __device__ __forceinline__ Pos step(Pos p, bool up) { return p + (up ? 1 : -1); }
+  __device__ __forceinline__ int load(Pos p) { return e[p]; }
+  __device__ __forceinline__ void store(Pos p, int v) { e[p] = v; }
+};
+
 // acc.cl:132-171 (intersect) and :173-217 (intersectIgnorePrimitiveIndex): same node order (near child
 // first by dirIsNeg[axis]), same box test (acc.cl:113-130, no clipping against the closest hit), leaf =
 // primitives[primitivesOffset] only (the reference's leaf loop never adds i; re-testing the same triangle
@@ -456,17 +476,14 @@ __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float 
 // ANYHIT (shadow rays, only when not counting work): the callers of a shadow ray read nothing but `hitType == 0`
 // (acc.cl:276, gi.cl:295,:351), so the walk may stop at the first accepted triangle -- same pixels, fewer node visits
 // than the reference algorithm performs.  The counting (STATS) instantiations never use it.
-template <int PROGRAM, bool DEEP, bool STATS, bool FINITE, bool ANYHIT, bool LDSSCENE = false>
+template <int PROGRAM, class STACK, bool STATS, bool FINITE, bool ANYHIT, bool LDSSCENE = false>
 __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool useIgnore, int ignore,
-                                     Hit& pl, Stack<DEEP>& st, Counters& c) {
-  // finite rays of the non-counting kernels walk the backend's own tree (lt_retree.hpp; == the caller's when there is none)
-  constexpr bool OWN = FINITE && !STATS && !LDSSCENE;
+                                     Hit& pl, STACK& st, Counters& c) {
   const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;
   const uint32_t negBits = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);   // dirIsNeg[axis] = bit `axis` (axis <= 2: set_scene)
-  const uint32_t* const rank8 = (OWN && !ANYHIT) ? sc.rank8 : nullptr;
   const int ign = useIgnore ? ignore : -1;   // leaf offsets are >= 0
   int cur = 0;
-  typename Stack<DEEP>::Pos sp = st.bottom();   // where the next entry goes
+  typename STACK::Pos sp = st.bottom();   // where the next entry goes
   int pend = -1;
   uint32_t pendCount = 0;
   bool alive = true;
@@ -478,11 +495,11 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
       const LdsF4 n = (LdsF4)(size_t)(sc.ldsNodes + ((uint32_t)cur << 5));
       a = ld_lds(n); b = ld_lds(n + 1);
     } else {
-      const float4* n = (const float4*)((const char*)(OWN ? sc.ownNodes : sc.nodes) + ((uint32_t)cur << 5));
+      const float4* n = (const float4*)((const char*)sc.nodes + ((uint32_t)cur << 5));
       a = n[0]; b = n[1];
     }
     // the entry below the top is read now, beside the node fetch, whether or not this node turns out to need it
-    const typename Stack<DEEP>::Pos below = st.below(sp);   // (the bottom row, unused, for a lane that is about to end)
+    const typename STACK::Pos below = st.below(sp);   // (the bottom row, unused, for a lane that is about to end)
     const int popped = st.load(below);
     if (STATS) c.nodes++;
     LT_WAVE_COUNT(wInner);
@@ -495,7 +512,7 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
       LT_WAVE_COUNT(wTri);
       if (STATS) c.tris += pendCount;    // the reference *calls* intersectTriangle primitiveCount times
       if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl, sc.fastRcp != 0u)
-                   : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, sc.fastRcp != 0u, rank8, negBits)) {
+                   : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, sc.fastRcp != 0u)) {
         pl.prim = pend;
         pl.hitType = 1;
         if (ANYHIT) return;
@@ -520,7 +537,45 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
     LT_WAVE_COUNT(wTri);
     if (STATS) c.tris += pendCount;
     if (LDSSCENE ? intersect_triangle_lds<PROGRAM>(sc.ldsTris, pend, ray, pl, sc.fastRcp != 0u)
-                 : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, sc.fastRcp != 0u, rank8, negBits)) {
+                 : intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, sc.fastRcp != 0u)) {
+      pl.prim = pend;
+      pl.hitType = 1;
+    }
+  }
+}
+
+// The per-lane walk over the backend's own tree (finite rays of the non-counting kernels; lt_retree.hpp says why any order over
+// any enclosing hierarchy finds the reference's set of leaves).  No stack: the tree is in pre-order, the left child follows its
+// parent, and an interior node carries its escape index -- where the walk continues when the node's box is missed or its subtree
+// is done -- so a step is "fetch, slab test, pick i + 1 or the escape".  Leaves are noted and tested at the top of the next
+// step, behind the issue of its loads, as in the stack walk above.  Closest-hit walks settle equal-t ties with the reference's
+// leaf order (SceneDev::rank8); any-hit walks (shadow rays: their callers read hitType only) stop at the first accepted hit.
+template <int PROGRAM, bool ANYHIT>
+__device__ inline void traverse_own_lane(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl) {
+  const uint32_t octant = (ix < 0.0f ? 1u : 0u) | (iy < 0.0f ? 2u : 0u) | (iz < 0.0f ? 4u : 0u);
+  const uint32_t* const rank8 = ANYHIT ? nullptr : sc.rank8;
+  const bool fast = sc.fastRcp != 0u;
+  const uint32_t end = sc.nOwn;
+  uint32_t cur = 0u;
+  int pend = -1;
+  do {
+    const float4* n = (const float4*)((const char*)sc.ownNodes + (cur << 5));   // (32-bit byte offset: checked at set_scene)
+    const float4 a = n[0], b = n[1];   // a = min.x min.y min.z max.x ; b = max.y max.z offset|escape count|axis<<16
+    if (pend >= 0) {
+      if (intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, fast, rank8, octant)) {
+        pl.prim = pend;
+        pl.hitType = 1;
+        if (ANYHIT) return;
+      }
+    }
+    const bool hit = box_test_finite(a.x, a.y, a.z, a.w, b.x, b.y, ray, ix, iy, iz);
+    const bool leaf = (__float_as_uint(b.w) & 0xffffu) != 0u;
+    const int off = __float_as_int(b.z);
+    pend = (hit && leaf && off != ign) ? off : -1;
+    cur = (leaf || hit) ? cur + 1u : (uint32_t)off;
+  } while (cur < end);
+  if (pend >= 0) {
+    if (intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, fast, rank8, octant)) {
       pl.prim = pend;
       pl.hitType = 1;
     }
@@ -592,9 +647,9 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
       const bool neg = (negBitsU >> ((meta >> 16) & 0xffu)) & 1u;   // dirIsNeg[axis], shared by the wave
       const int farChild = neg ? (int)ci + 1 : off;
       if (lane == leader) {   // any lane may be switched off (image edge): the first active one writes the entry
-        ldsWave[sp * kBlock + 0] = farChild;
-        ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmask;
-        ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmask >> 32);
+        ldsWave[sp * kPacketEntry + 0] = farChild;
+        ldsWave[sp * kPacketEntry + 1] = (int)(uint32_t)hmask;
+        ldsWave[sp * kPacketEntry + 2] = (int)(uint32_t)(hmask >> 32);
       }
       sp++;
       cur = neg ? off : (int)ci + 1;
@@ -617,9 +672,9 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
     }
     if (sp == 0) break;
     sp--;
-    cur = __builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 0]);      // same address in every lane: broadcast reads
-    mask = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 1]) |
-           ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 2]) << 32);
+    cur = __builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 0]);      // same address in every lane: broadcast reads
+    mask = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 1]) |
+           ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 2]) << 32);
   }
 }
 
@@ -695,9 +750,9 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
         } else {
           if (hmF != 0ull) {   // the far child waits for the near subtree
             // (every active lane stores the same three dwords at the same address: no exec juggling for a "leader")
-            ldsWave[sp * kBlock + 0] = (int)refF;
-            ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmF;
-            ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmF >> 32);
+            ldsWave[sp * kPacketEntry + 0] = (int)refF;
+            ldsWave[sp * kPacketEntry + 1] = (int)(uint32_t)hmF;
+            ldsWave[sp * kPacketEntry + 2] = (int)(uint32_t)(hmF >> 32);
             sp++;
           }
           cur = refN;
@@ -721,9 +776,9 @@ __device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray,
     while (!haveNext) {
       if (sp == 0) return;
       sp--;
-      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 0]);
-      const u64 m = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 1]) |
-                    ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 2]) << 32);
+      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 0]);
+      const u64 m = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 1]) |
+                    ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 2]) << 32);
       if (e & kLeafTag) {
         leaf_test(e & 0x7fffffffu, m);
       } else {
@@ -800,9 +855,9 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
               leaf_test(refR & 0x7fffffffu, hmR);
               if (openMask == 0ull) return;
             } else {   // the right child waits
-              ldsWave[sp * kBlock + 0] = (int)refR;
-              ldsWave[sp * kBlock + 1] = (int)(uint32_t)hmR;
-              ldsWave[sp * kBlock + 2] = (int)(uint32_t)(hmR >> 32);
+              ldsWave[sp * kPacketEntry + 0] = (int)refR;
+              ldsWave[sp * kPacketEntry + 1] = (int)(uint32_t)hmR;
+              ldsWave[sp * kPacketEntry + 2] = (int)(uint32_t)(hmR >> 32);
               sp++;
             }
           }
@@ -821,9 +876,9 @@ __device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ra
       }
       if (openMask == 0ull || sp == 0) return;   // every lane has its occluder, or nothing is left to visit
       sp--;
-      cur = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 0]);
-      mask = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 1]) |
-             ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kBlock + 2]) << 32);
+      cur = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 0]);
+      mask = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 1]) |
+             ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 2]) << 32);
     }
   };
   walk();
@@ -911,9 +966,22 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
       traverse_packet_pairs_anyhit<PROGRAM>(sc, ray, ix, iy, iz, ign, pl, row);
       return;
     }
-    traverse_nodes_impl<PROGRAM, DEEP, STATS, true, ANYHIT, LDSSCENE>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
-  } else {   // e.g. the image-centre column/row, where a direction component is exactly 0
-    traverse_nodes_impl<PROGRAM, DEEP, STATS, false, ANYHIT, LDSSCENE>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
+    if constexpr (!STATS && !LDSSCENE) {
+      if (sc.rank8 != nullptr) {   // (the scene has a tree of the backend's own: lt_hip_set_scene)
+        traverse_own_lane<PROGRAM, ANYHIT>(sc, ray, ix, iy, iz, useIgnore ? ignore : -1, pl);
+        return;
+      }
+    }
+  }
+  // In the reference's order over the caller's tree: the counting kernels and the LDS-resident small scenes with the LDS stack,
+  // the others -- rays with a non-finite component, e.g. the image-centre column / row where a direction component is exactly
+  // 0, and scenes without a tree of the backend's own -- with the stack in private memory.
+  if constexpr (STATS || LDSSCENE) {
+    if (__all(finite)) traverse_nodes_impl<PROGRAM, Stack<DEEP>, STATS, true, ANYHIT, LDSSCENE>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
+    else traverse_nodes_impl<PROGRAM, Stack<DEEP>, STATS, false, ANYHIT, LDSSCENE>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, st, c);
+  } else {
+    ScratchStack ss;
+    traverse_nodes_impl<PROGRAM, ScratchStack, false, false, ANYHIT, false>(sc, ray, ix, iy, iz, useIgnore, ignore, pl, ss, c);
   }
 }
 

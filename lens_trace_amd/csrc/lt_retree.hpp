@@ -226,6 +226,19 @@ inline int build(const void* nodes, uint32_t n_nodes, int maxHeight, int slack, 
   return height;
 }
 
+// Replaces every interior node's second-child index by its escape index: the node that follows its subtree in pre-order
+// (nodes.size() after the last one) -- what a stackless walk needs (lt_device.hpp, traverse_own_lane).  The second child is
+// not lost: it is the escape of the left child, i + 1.
+inline void thread(std::vector<Node>& nodes) {
+  const size_t n = nodes.size();
+  std::vector<uint32_t> esc(n);
+  for (size_t i = n; i-- > 0;) {
+    esc[i] = nodes[i].cnt != 0 ? (uint32_t)i + 1u : esc[(size_t)nodes[i].off];   // (children sit behind their parent: already known)
+  }
+  for (size_t i = 0; i < n; i++)
+    if (nodes[i].cnt == 0) nodes[i].off = (int32_t)esc[i];
+}
+
 // rank8[8 * primitive + octant]: position of the primitive's (first) leaf in the caller's tree walked depth-first, near child
 // first, by a ray whose direction signs are `octant` (bit a = component a negative: the reference's dirIsNeg[node->axis],
 // acc.cl:150-160).  0xffffffff for primitives no leaf refers to.

@@ -16,7 +16,7 @@
 //     stands for "> 0", exact for every non-NaN input, and a packet is only formed from rays that cannot produce a NaN
 //     (traverse_camera / traverse: all origins and inverse directions finite);
 //   * branches test SCC straight from the mask arithmetic; the wave-uniform stack (child reference + 64-bit lane mask per
-//     entry, one row of the wave's LDS stack each) is written / read with three ds_*_b32 of identical data per lane;
+//     entry, 16 bytes apart in the wave's LDS) is written / read with three ds_*_b32 of identical data per lane;
 //   * the triangle test (acc.cl:72-111 on the re-tiled 48-byte triangle: cross = fma(a, b, -(c * d)), dot = fma chain + the
 //     `w` terms, IEEE 1 / det by the div_scale / rcp / fma / div_fmas / div_fixup sequence hipcc emits for `1.0f / x` -- or,
 //     for the as-shipped math flavour (operand `fast`), the 2.5-ulp form the reference's NULL build options give it -- each
@@ -113,7 +113,7 @@ typedef unsigned long long lt_u64;
 
 // push (reference REF, lane mask LO:HI) on the wave-uniform stack
 #define LT_ASM_PUSH(REF, LO, HI)                    \
-  "v_lshl_add_u32 %[t0], %[sp], 8, %[lds]\n"        \
+  "v_lshl_add_u32 %[t0], %[sp], 4, %[lds]\n"        \
   "v_mov_b32_e32 %[t1], " REF "\n"                  \
   "v_mov_b32_e32 %[t2], " LO "\n"                   \
   "v_mov_b32_e32 %[t3], " HI "\n"                   \
@@ -133,7 +133,7 @@ typedef unsigned long long lt_u64;
 #define LT_ASM_POP_TOP                                      \
   "s_mov_b64 exec, " LT_R_EXEC "\n"                         \
   "s_sub_u32 %[sp], %[sp], 1\n"                             \
-  "v_lshl_add_u32 %[t0], %[sp], 8, %[lds]\n"                \
+  "v_lshl_add_u32 %[t0], %[sp], 4, %[lds]\n"                \
   "ds_read_b32 %[t1], %[t0]\n"                              \
   "ds_read_b32 %[t2], %[t0] offset:4\n"                     \
   "ds_read_b32 %[t3], %[t0] offset:8\n"                     \
