@@ -30,24 +30,39 @@ __global__ void lt_retile_kernel(const float* __restrict__ prims, float4* __rest
   tris[3 * (size_t)i + 2] = make_float4(p[8] - az, 0.0f, 0.0f, 0.0f);
 }
 
-// Child-pair records for the packet walks (traverse_packet_pairs, traverse_packet_pairs_anyhit): pairs[i] = (record of node
-// i + 1, record of node secondChildOffset(i)) for every interior node i, each child's `offset` field replaced by what the walks
-// put on their stack: index | axis << 29 for an interior child, 0x80000000 | primitive offset for a leaf.
-// Leaves get no record (their slot stays unwritten and is never read).
-__global__ void lt_pair_kernel(const float4* __restrict__ nodes, float4* __restrict__ pairs, uint32_t n) {
+// The records of the packet walks (lt_walk_asm.hpp, packet_walk_cpp), one 64-byte slot per node of the backend's own tree:
+//   interior node i: [left child's box, its reference, -][right child's box, its reference, -], the boxes pushed outwards by
+//                    2^-21 of each bound and one float more (the walks' conservative test needs lo' <= lo - 6 * 2^-24 |lo|),
+//                    a reference = the child's index, with bit 31 set when the child is a leaf;
+//   leaf i:          [A, e1 = B - A, e2 = C - A of its triangle (lt_retile_kernel's arithmetic)][the leaf's own box, bit for
+//                    bit][the primitive offset]: what the reference's leaf test needs, in one scalar load.
+__device__ __forceinline__ float lt_outwards(float b, bool up) {
+  const float t = up ? b + __builtin_fabsf(b) * 0x1p-21f : b - __builtin_fabsf(b) * 0x1p-21f;
+  uint32_t u = __float_as_uint(t);
+  if ((u & 0x7fffffffu) == 0u) return __uint_as_float((up ? 0u : 0x80000000u) | 1u);    // +-0 -> the smallest denormal of that side
+  const bool away = (t > 0.0f) == up;   // moving away from zero = the next larger magnitude
+  u = away ? u + 1u : u - 1u;
+  return __uint_as_float(u);
+}
+__global__ void lt_own_pair_kernel(const float4* __restrict__ nodes, const float* __restrict__ prims, float4* __restrict__ pairs, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float4 b = nodes[2 * (size_t)i + 1];
-  if ((__float_as_uint(b.w) & 0xffffu) != 0u) return;
+  const float4 a = nodes[2 * (size_t)i], b = nodes[2 * (size_t)i + 1];
+  if ((__float_as_uint(b.w) & 0xffffu) != 0u) {
+    const float* p = prims + 19 * (size_t)__float_as_uint(b.z);
+    const float ax = p[0], ay = p[1], az = p[2];
+    pairs[4 * (size_t)i + 0] = make_float4(ax, ay, az, p[3] - ax);
+    pairs[4 * (size_t)i + 1] = make_float4(p[4] - ay, p[5] - az, p[6] - ax, p[7] - ay);
+    pairs[4 * (size_t)i + 2] = make_float4(p[8] - az, a.x, a.y, a.z);
+    pairs[4 * (size_t)i + 3] = make_float4(a.w, b.x, b.y, b.z);
+    return;
+  }
   const uint32_t child[2] = {i + 1u, __float_as_uint(b.z)};
   for (int k = 0; k < 2; k++) {
-    const float4 ca = nodes[2 * (size_t)child[k]];
-    float4 cb = nodes[2 * (size_t)child[k] + 1];
-    const uint32_t cmeta = __float_as_uint(cb.w);
-    cb.z = __uint_as_float((cmeta & 0xffffu) == 0u ? (child[k] | (((cmeta >> 16) & 3u) << 29))      // interior: index | axis << 29
-                                                    : (0x80000000u | __float_as_uint(cb.z)));        // leaf: tagged primitive offset
-    pairs[4 * (size_t)i + 2 * k] = ca;
-    pairs[4 * (size_t)i + 2 * k + 1] = cb;
+    const float4 ca = nodes[2 * (size_t)child[k]], cb = nodes[2 * (size_t)child[k] + 1];
+    const bool leaf = (__float_as_uint(cb.w) & 0xffffu) != 0u;
+    pairs[4 * (size_t)i + 2 * k] = make_float4(lt_outwards(ca.x, false), lt_outwards(ca.y, false), lt_outwards(ca.z, false), lt_outwards(ca.w, true));
+    pairs[4 * (size_t)i + 2 * k + 1] = make_float4(lt_outwards(cb.x, true), lt_outwards(cb.y, true), __uint_as_float(child[k] | (leaf ? 0x80000000u : 0u)), 0.0f);
   }
 }
 
@@ -100,7 +115,7 @@ struct lt_hip_context {
   int device = -1;
   std::string err;
   hipStream_t stream = nullptr;      // own stream for lt_hip_render
-  void *d_nodes = nullptr, *d_pairs = nullptr, *d_tris = nullptr, *d_prims = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+  void *d_nodes = nullptr, *d_tris = nullptr, *d_prims = nullptr, *d_mats = nullptr, *d_lights = nullptr;
   void *d_nodes2 = nullptr, *d_pairs2 = nullptr;   // the backend's own tree over the scene's leaves (lt_retree.hpp), or null
   void* d_rank8 = nullptr;                         // with it: the reference's leaf order per direction-sign octant (SceneDev::rank8)
   int height2 = 0;                                 // its height
@@ -193,7 +208,7 @@ extern "C" int lt_hip_create(int device_index, lt_hip_context** out_ctx) {
 }
 
 static void free_scene(lt_hip_context* ctx) {
-  for (void** p : {&ctx->d_nodes, &ctx->d_pairs, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights, &ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_rank8}) {
+  for (void** p : {&ctx->d_nodes, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights, &ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_rank8}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -459,13 +474,9 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
   hipLaunchKernelGGL(lt_retile_kernel, dim3((n_prims + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->d_prims,
                      (float4*)ctx->d_tris, n_prims);
   LT_HIP_CHECK(ctx, hipGetLastError());
-  if ((uint64_t)n_nodes * 64 > 0xffffffffull) return fail(ctx, LT_ERR_BAD_SCENE, "too many nodes for the child-pair records (64 bytes each, 32-bit byte offsets)");
-  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pairs, (size_t)n_nodes * 64));
-  hipLaunchKernelGGL(lt_pair_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes,
-                     (float4*)ctx->d_pairs, n_nodes);
-  LT_HIP_CHECK(ctx, hipGetLastError());
   // The backend's own hierarchy over the same leaves (lt_retree.hpp says why the pixels cannot change), for every finite ray of
-  // the non-counting kernels.  LT_RETREE=0 keeps every walk on the caller's tree.
+  // the non-counting kernels.  LT_RETREE=0 keeps the caller's splits (same structures, same walks).  A scene whose boxes do not
+  // nest gets none: its rays walk the caller's tree one by one, in the reference's order.
   ctx->height2 = 0;
   ctx->retree_ms = 0.0f;
   {
@@ -473,15 +484,16 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
     std::vector<lt_retree::Node> own;
     const auto t0 = std::chrono::steady_clock::now();
     const char* sl = getenv("LT_RETREE_SLACK");
-    const int h2 = (re && atoi(re) == 0) ? -1 : lt_retree::build(nodes, n_nodes, kLdsStack, sl ? atoi(sl) : 2, own);
+    // (height <= 30: the packet walks' stack, one VGPR, holds 2 * height + 2 entries at most; LT_RETREE=0: the caller's splits)
+    const int h2 = (re && atoi(re) == 0) ? lt_retree::copy(nodes, n_nodes, 30, own) : lt_retree::build(nodes, n_nodes, 30, sl ? atoi(sl) : 2, own);
     if (h2 >= 0) {
       ctx->retree_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
       const uint32_t n2 = (uint32_t)own.size();
       LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_nodes2, (size_t)n2 * 32));
       LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pairs2, (size_t)n2 * 64));
       LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_nodes2, own.data(), (size_t)n2 * 32, hipMemcpyHostToDevice));
-      hipLaunchKernelGGL(lt_pair_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2,
-                         (float4*)ctx->d_pairs2, n2);
+      hipLaunchKernelGGL(lt_own_pair_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2,
+                         (const float*)ctx->d_prims, (float4*)ctx->d_pairs2, n2);
       LT_HIP_CHECK(ctx, hipGetLastError());
       LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
       lt_retree::thread(own);   // (the pair records are made: now the form the stackless per-lane walks read)
@@ -879,9 +891,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
 
   SceneDev sc;
   sc.nodes = (const float4*)ctx->d_nodes;
-  sc.pairs = (const float4*)ctx->d_pairs;
-  sc.ownNodes = ctx->d_nodes2 ? (const float4*)ctx->d_nodes2 : sc.nodes;
-  sc.ownPairs = ctx->d_pairs2 ? (const float4*)ctx->d_pairs2 : sc.pairs;
+  sc.ownNodes = (const float4*)ctx->d_nodes2;
+  sc.ownPairs = (const float4*)ctx->d_pairs2;
   sc.rank8 = (const uint32_t*)ctx->d_rank8;
   sc.nOwn = ctx->d_rank8 ? ctx->n_nodes2 : 0u;
   sc.tris = (const float4*)ctx->d_tris;
@@ -1011,8 +1022,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       } else {
         // Time the three shadow-ray walks (packets, per lane, chosen per wavefront) once per (scene, program, image geometry), ahead
         // of a launch whose output they may scribble on (it overwrites what it writes, as every fused launch does): the launch's
-        // FIRST frame alone runs six times -- the three in turn, twice -- and each walk is given the faster of its two runs, so the
-        // first, cache-cold launch of a scene and a one-off hiccup decide nothing; then the launch itself runs once, with the winner.
+        // FIRST FOUR frames run six times -- the three walks in turn, twice -- and each walk is given the faster of its two runs, so
+        // the first, cache-cold launch of a scene and a one-off hiccup decide nothing; then the launch itself runs once, with the winner.
         const bool calibrate = shadowMode < 0 && persistent && !stats && ctx->bvh_height <= kLdsStack && fp.accumulateN < 0;
         auto launch_render = [&](const FrameParams& fpl, dim3 g) {
           switch (d->program) {
@@ -1027,7 +1038,9 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         if (calibrate) {
           for (hipEvent_t& e : ctx->cal_ev) if (!e) LT_HIP_CHECK(ctx, hipEventCreate(&e));
           FrameParams f1 = fp;
-          f1.fusedFrames = 1;
+          // (up to four of the call's frames: one frame alone ends when its slowest squares do -- the image's centre row and
+          // column, whose non-finite rays walk the caller's tree -- whatever the other 130 000 do)
+          f1.fusedFrames = std::min(fp.fusedFrames, 4u);
           const dim3 g1((uint32_t)std::min<uint64_t>(nblocks, resident));
           static const uint32_t kOrder[3] = {1u, 0u, 2u};
           for (int pass = 0; pass < 6; pass++) {
@@ -1041,6 +1054,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
           LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->cal_ev[11]));
           for (int k = 0; k < 6; k++) LT_HIP_CHECK(ctx, hipEventElapsedTime(&t[k], ctx->cal_ev[2 * k], ctx->cal_ev[2 * k + 1]));
           const float packets = std::min(t[0], t[3]), perLane = std::min(t[1], t[4]), perWave = std::min(t[2], t[5]);
+          if (getenv("LT_DEBUG_CALIBRATION"))
+            fprintf(stderr, "shadow-walk timing (ms): packets %.3f %.3f, per lane %.3f %.3f, per wavefront %.3f %.3f\n", t[0], t[3], t[1], t[4], t[2], t[5]);
           float best = perLane;                                  // (ties keep the simpler walk: per lane, then packets)
           shadowMode = 0;
           if (packets < 0.99f * best) { shadowMode = 1; best = packets; }

@@ -60,11 +60,10 @@ struct Lights { uint32_t count; uint32_t primitives[64]; };                     
 //   prims : the reference's 76-byte Primitive array, verbatim (shading reads positions+normals+material).
 struct SceneDev {
   const float4* nodes;
-  const float4* pairs;      // per interior node index: the records of its two children side by side (64 B; lt_pair_kernel)
-  // The backend's own tree over the caller's leaves (lt_retree.hpp: same leaves, same boxes, binned-SAH hierarchy, same two
-  // layouts), walked by every finite ray of the non-counting kernels; == nodes / pairs when the scene has none.
-  const float4* ownNodes;
-  const float4* ownPairs;
+  // The backend's own tree over the caller's leaves (lt_retree.hpp: same leaves, same boxes, binned-SAH hierarchy), walked by
+  // every finite ray of the non-counting kernels; null (and rank8 null) when the scene has none: its boxes do not nest.
+  const float4* ownNodes;   // 32-byte nodes in the caller's layout, an interior node's escape index in place of its second child
+  const float4* ownPairs;   // 64-byte records of the packet walks (lt_own_pair_kernel)
   // With it, for the closest-hit walks: rank8[8 * primitive + octant] = position of the primitive's leaf in the REFERENCE's
   // depth-first order for rays of that direction-sign octant.  intersectTriangle keeps the first of two hits with equal t
   // (`t < payload.t`, acc.cl:104); a walk that meets the leaves in another order keeps the one with the lower rank.  Null
@@ -678,211 +677,100 @@ __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float
   }
 }
 
-// The packet walk over child-pair records: sc.pairs[i] holds the records of interior node i's two children side by side
-// (left = i + 1, right = secondChildOffset), an interior child's `offset` field replaced by that child's own index, so one
-// 64-byte scalar load serves two slab tests and the walk makes half the dependent fetches.  Order per lane is the
-// reference's: the near child's subtree (or leaf) completely before the far child's; a far child that must wait goes on
-// the wave-uniform stack with the mask of the lanes that hit it (a leaf as 0x80000000 | primitive offset).
-// NEG is the direction-sign octant the wave's rays share (bit a = component a negative; traverse_camera switches on it): with
-// the signs known at compile time the slab test picks each axis' entry plane directly (box_mask<NEG>).
-template <int PROGRAM, int NEG>
-__device__ inline void traverse_packet_pairs(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, Hit& pl, int* ldsWave) {
+// ---- the packet walks of the non-counting kernels, over the backend's own tree (lt_walk_asm.hpp describes the walk and proves
+// its conservative interior test; this is its plain-C++ form: the any-hit walk of waves whose rays do not share a direction-sign
+// octant (NEG < 0), and every packet walk of a build with -DLT_NO_ASM_WALKS).  sc.ownPairs[i]: interior node i -> its two
+// children's boxes (pushed outwards) and references, leaf i -> the leaf's own box, its re-tiled triangle, its primitive offset
+// (lt_own_pair_kernel).  The wave-uniform stack -- one dword per entry -- sits in the wave's two LDS rows.
+struct PacketRayC { float px, py, pz, mg; };
+template <int NEG>
+__device__ __forceinline__ unsigned long long box_mask_cheap(float lox, float loy, float loz, float hix, float hiy, float hiz, float ix, float iy,
+                                                            float iz, const PacketRayC& pr) {
+  float tEnter, tExit;
+  if (NEG >= 0) {
+    const float nearX = (NEG & 1) ? hix : lox, farX = (NEG & 1) ? lox : hix;
+    const float nearY = (NEG & 2) ? hiy : loy, farY = (NEG & 2) ? loy : hiy;
+    const float nearZ = (NEG & 4) ? hiz : loz, farZ = (NEG & 4) ? loz : hiz;
+    tEnter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(nearX, ix, -pr.px), __builtin_fmaf(nearY, iy, -pr.py)), __builtin_fmaf(nearZ, iz, -pr.pz));
+    tExit = __builtin_fminf(__builtin_fminf(__builtin_fmaf(farX, ix, -pr.px), __builtin_fmaf(farY, iy, -pr.py)), __builtin_fmaf(farZ, iz, -pr.pz));
+  } else {   // fma is monotonic in the bound and lo' <= hi': the smaller product is the near one
+    const float tx0 = __builtin_fmaf(lox, ix, -pr.px), tx1 = __builtin_fmaf(hix, ix, -pr.px);
+    const float ty0 = __builtin_fmaf(loy, iy, -pr.py), ty1 = __builtin_fmaf(hiy, iy, -pr.py);
+    const float tz0 = __builtin_fmaf(loz, iz, -pr.pz), tz1 = __builtin_fmaf(hiz, iz, -pr.pz);
+    tEnter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)), __builtin_fminf(tz0, tz1));
+    tExit = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fmaxf(tz0, tz1));
+  }
+  return __builtin_amdgcn_ballot_w64(tExit + pr.mg >= __builtin_fmaxf(tEnter, __uint_as_float(1u)));
+}
+
+template <int PROGRAM, int NEG, bool ANYHIT>
+__device__ inline void packet_walk_cpp(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl, int* ldsWave) {
   using u64 = unsigned long long;
-  constexpr uint32_t kLeafTag = 0x80000000u;
-  const ConstF4 nodes = (ConstF4)(unsigned long long)sc.ownNodes;
-  const ConstF4 pairs = (ConstF4)(unsigned long long)sc.ownPairs;
-  const ConstF4 tris = (ConstF4)(unsigned long long)sc.tris;
+  const __attribute__((address_space(4))) char* const pairs = (const __attribute__((address_space(4))) char*)(unsigned long long)sc.ownPairs;
   const int lane = (int)__lane_id();
-  constexpr uint32_t negBitsU = (uint32_t)NEG;   // the direction signs the whole wave shares, a compile-time constant here
-  auto leaf_test = [&](uint32_t off, u64 m) {
-    const ConstF4 t = tris + 3 * (size_t)off;
-    const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
-#ifndef LT_BRANCHY_PACKET_LEAF
-    intersect_triangle_packet<PROGRAM>(t0, t1, t2, ray, pl, ((m >> lane) & 1ull) != 0ull, (int)off, sc.fastRcp != 0u, sc.rank8, negBitsU);
-#else
-    if ((m >> lane) & 1ull) {
-      if (intersect_triangle_data<PROGRAM>(t0, t1, t2, ray, pl, sc.fastRcp != 0u, sc.rank8, negBitsU, (int)off)) {
-        pl.prim = (int)off;
-        pl.hitType = 1;
+  PacketRayC pr;
+  pr.px = ray.o.x * ix; pr.py = ray.o.y * iy; pr.pz = ray.o.z * iz;
+  pr.mg = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(pr.px), __builtin_fabsf(pr.py)), __builtin_fabsf(pr.pz)) * 0x1p-19f + 0x1p-140f;
+  const float tmax = pl.t;
+  const bool fast = sc.fastRcp != 0u;
+  u64 live = __builtin_amdgcn_ballot_w64(true);   // any-hit: the lanes still looking for an occluder
+  uint32_t cur = 0u;
+  int sp = 0;
+  for (;;) {
+    const F16v r = *(ConstF16)(pairs + (cur << 6));   // (bit 31 of a leaf reference falls off the 32-bit byte offset)
+    if ((int)cur >= 0) {
+      const u64 hmL = box_mask_cheap<NEG>(r.s0, r.s1, r.s2, r.s3, r.s4, r.s5, ix, iy, iz, pr) & live;
+      const u64 hmR = box_mask_cheap<NEG>(r.s8, r.s9, r.sa, r.sb, r.sc, r.sd, ix, iy, iz, pr) & live;
+      // (every active lane stores the same dword at the same address: no exec juggling for a "leader")
+      if (hmL != 0ull) ldsWave[sp++] = __float_as_int(r.s6);
+      if (hmR != 0ull) ldsWave[sp++] = __float_as_int(r.se);
+    } else {
+      // the leaf's own box, the reference's own test
+      const u64 m = box_mask<NEG>(r.s9, r.sa, r.sb, r.sc, r.sd, r.se, ray, ix, iy, iz) & live;
+      const int prim = __float_as_int(r.sf);
+      if (m != 0ull) {
+        const float4 t0 = make_float4(r.s0, r.s1, r.s2, r.s3), t1 = make_float4(r.s4, r.s5, r.s6, r.s7), t2 = make_float4(r.s8, 0.0f, 0.0f, 0.0f);
+        const bool active = ((m >> lane) & 1ull) != 0ull && (!ANYHIT || prim != ign);
+        if constexpr (ANYHIT) {
+          live &= ~__builtin_amdgcn_ballot_w64(intersect_triangle_anyhit<PROGRAM>(t0, t1, t2, ray, tmax, active, fast));
+          if (live == 0ull) break;
+        } else {
+          intersect_triangle_packet<PROGRAM>(t0, t1, t2, ray, pl, active, prim, fast, sc.rank8, (uint32_t)(NEG < 0 ? 0 : NEG));
+        }
       }
     }
-#endif
-  };
-  u64 mask;
-  uint32_t cur;   // interior node: index | axis << 29
-  {
-    const F8v nd = *(ConstF8)(nodes);
-    mask = box_mask<NEG>(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz);
-    if (mask == 0ull) return;
-    const uint32_t meta = __float_as_uint(nd.s7);
-    if ((meta & 0xffffu) != 0u) { leaf_test(__float_as_uint(nd.s6), mask); return; }
-    cur = ((meta >> 16) & 3u) << 29;
+    if (sp == 0) break;
+    cur = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[--sp]);
   }
+  if constexpr (ANYHIT) pl.hitType = ((live >> lane) & 1ull) != 0ull ? pl.hitType : 1;
+}
+
+// One packet walk: the hand-written form when the wave's rays share the direction-sign octant NEG, the C++ form otherwise.
+template <int PROGRAM, int NEG, bool ANYHIT>
+__device__ __forceinline__ void packet_walk(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl, int* ldsWave) {
 #ifndef LT_NO_ASM_WALKS
-  {
-    // everything below the root in hand-written, scalar-controlled form (lt_walk_asm.hpp)
+  if constexpr (NEG >= 0) {
     const float eps = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
                       : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
-    const uint32_t ldsBase = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)ldsWave;
-    packet_closest_walk<NEG>((const void*)sc.ownPairs, (const void*)sc.tris, (const void*)sc.rank8, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y, ray.d.z,
-                             ray.d.w, eps, sc.fastRcp, ldsBase, cur, mask, pl.t, pl.u, pl.v, pl.prim, pl.hitType);
+    if constexpr (ANYHIT) {
+      const unsigned long long open = packet_anyhit_walk<NEG>((const void*)sc.ownPairs, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y,
+                                                              ray.d.z, ray.d.w, pl.t, ign, eps, sc.fastRcp, __builtin_amdgcn_ballot_w64(true));
+      pl.hitType = ((open >> __lane_id()) & 1ull) != 0ull ? pl.hitType : 1;
+    } else {
+      packet_closest_walk<NEG>((const void*)sc.ownPairs, (const void*)sc.rank8, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y,
+                               ray.d.z, ray.d.w, eps, sc.fastRcp, pl.t, pl.u, pl.v, pl.prim, pl.hitType);
+    }
     return;
   }
 #endif
-  int sp = 0;
-  for (;;) {
-    const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));
-    const uint32_t axis = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur >> 29));
-    const F16v pr = *(ConstF16)((const __attribute__((address_space(4))) char*)pairs + (ci << 6));   // (32-bit byte offset: < 4 GiB of records)
-    const u64 hmL = box_mask<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz) & mask;
-    const u64 hmR = box_mask<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz) & mask;
-    // everything below is wave-uniform.  One scalar branch on dirIsNeg[axis] and the rest written out for each order costs
-    // fewer scalar instructions than selecting near / far for six values (the scalar unit is what limits this loop)
-    const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
-    bool haveNext = false;
-    // the records' `offset` fields come ready to use (lt_pair_kernel): a leaf as 0x80000000 | primitive offset, an interior
-    // child as index | axis << 29 -- what goes on the stack and into `cur` as is.  Returns true when `cur` / `mask` hold the
-    // next interior node.
-    auto visit = [&](u64 hmN, u64 hmF, uint32_t refN, uint32_t refF) -> bool {
-      if (hmN != 0ull) {
-        if ((int)refN < 0) {
-          leaf_test(refN & 0x7fffffffu, hmN);
-        } else {
-          if (hmF != 0ull) {   // the far child waits for the near subtree
-            // (every active lane stores the same three dwords at the same address: no exec juggling for a "leader")
-            ldsWave[sp * kPacketEntry + 0] = (int)refF;
-            ldsWave[sp * kPacketEntry + 1] = (int)(uint32_t)hmF;
-            ldsWave[sp * kPacketEntry + 2] = (int)(uint32_t)(hmF >> 32);
-            sp++;
-          }
-          cur = refN;
-          mask = hmN;
-          return true;
-        }
-      }
-      if (hmF != 0ull) {   // (the near child was missed, or was a leaf and is done)
-        if ((int)refF < 0) {
-          leaf_test(refF & 0x7fffffffu, hmF);
-        } else {
-          cur = refF;
-          mask = hmF;
-          return true;
-        }
-      }
-      return false;
-    };
-    if (((negBitsU >> axis) & 1u) != 0u) haveNext = visit(hmR, hmL, refR, refL);
-    else haveNext = visit(hmL, hmR, refL, refR);
-    while (!haveNext) {
-      if (sp == 0) return;
-      sp--;
-      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 0]);
-      const u64 m = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 1]) |
-                    ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 2]) << 32);
-      if (e & kLeafTag) {
-        leaf_test(e & 0x7fffffffu, m);
-      } else {
-        cur = e;
-        mask = m;
-        haveNext = true;
-      }
-    }
-  }
+  packet_walk_cpp<PROGRAM, NEG, ANYHIT>(sc, ray, ix, iy, iz, ign, pl, ldsWave);
 }
 
-// Any-hit packet walk over the child-pair records for shadow rays (non-counting kernels): their callers read only hitType
-// (acc.cl:276, gi.cl:295,:351), so neither the order of the walk nor which occluder is found matters.  The wave walks the
-// union of its rays' node sets, left child first; a lane drops out at its first accepted triangle; the walk ends when the
-// stack is empty or no lane is left.  Whether this beats 64 independent per-lane walks depends on how coherent a scene's
-// shadow rays are -- 8x8 neighbouring surface points looking at one small light: +15 % of the whole frame on the 1 M-triangle
-// wall; a large light close to curved geometry, or surface points scattered in depth: -41 % (blob in a box), -32 % (triangle
-// soup) -- so the host times both on a scene's first frame and sets SceneDev::shadowPackets (lt_capi.hip).
-template <int PROGRAM, int NEG = -1>   // NEG >= 0: all rays of the wave share the direction-sign octant NEG (box_mask<NEG>)
-__device__ inline void traverse_packet_pairs_anyhit(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl,
-                                                    int* ldsWave) {
-  using u64 = unsigned long long;
-  const ConstF4 nodes = (ConstF4)(unsigned long long)sc.ownNodes;
-  const ConstF4 pairs = (ConstF4)(unsigned long long)sc.ownPairs;
-  const ConstF4 tris = (ConstF4)(unsigned long long)sc.tris;
-  const int lane = (int)__lane_id();
-  const float tmax = pl.t;
-  // The only state a leaf test changes is the wave's mask of lanes that still look for an occluder: it lives in a scalar
-  // register pair, no payload travels through the loop (pl.hitType is set from it at the end; pl.prim / t / u / v keep their
-  // initial values: the callers read hitType only).
-  u64 openMask = __builtin_amdgcn_ballot_w64(true);
-  auto leaf_test = [&](uint32_t off, u64 m) {
-    const ConstF4 t = tris + 3 * (size_t)off;
-    const float4 t0 = ld_const(t), t1 = ld_const(t + 1), t2 = ld_const(t + 2);
-    const bool active = (((m & openMask) >> lane) & 1ull) != 0ull && (int)off != ign;
-    openMask &= ~__builtin_amdgcn_ballot_w64(intersect_triangle_anyhit<PROGRAM>(t0, t1, t2, ray, tmax, active, sc.fastRcp != 0u));
-  };
-  auto walk = [&]() {
-    u64 mask;
-    uint32_t cur = 0u;
-    {
-      const F8v nd = *(ConstF8)(nodes);
-      mask = box_mask<NEG>(nd.s0, nd.s1, nd.s2, nd.s3, nd.s4, nd.s5, ray, ix, iy, iz);
-      if (mask == 0ull) return;
-      const uint32_t meta = __float_as_uint(nd.s7);
-      if ((meta & 0xffffu) != 0u) { leaf_test(__float_as_uint(nd.s6), mask); return; }
-    }
-#ifndef LT_NO_ASM_WALKS
-    if constexpr (NEG >= 0) {
-      // everything below the root in hand-written, scalar-controlled form (lt_walk_asm.hpp)
-      const float epsBits = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
-                            : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
-      const uint32_t ldsBase = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)ldsWave;
-      openMask = packet_anyhit_walk<NEG>((const void*)sc.ownPairs, (const void*)sc.tris, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y,
-                                         ray.d.z, ray.d.w, tmax, ign, epsBits, sc.fastRcp, ldsBase, mask, openMask);
-      return;
-    }
-#endif
-    int sp = 0;
-    for (;;) {
-      const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & 0x1fffffffu));   // (the axis bits are not needed here)
-      const F16v pr = *(ConstF16)((const __attribute__((address_space(4))) char*)pairs + (ci << 6));
-      const u64 live = mask & openMask;
-      const u64 hmL = box_mask<NEG>(pr.s0, pr.s1, pr.s2, pr.s3, pr.s4, pr.s5, ray, ix, iy, iz) & live;
-      const u64 hmR = box_mask<NEG>(pr.s8, pr.s9, pr.sa, pr.sb, pr.sc, pr.sd, ray, ix, iy, iz) & live;
-      const uint32_t refL = __float_as_uint(pr.s6), refR = __float_as_uint(pr.se);
-      // (lt_pair_kernel tags leaves: 0x80000000 | primitive offset; plain nested ifs keep the control flow on SCC branches)
-      if (hmL != 0ull) {
-        if ((int)refL < 0) {
-          leaf_test(refL & 0x7fffffffu, hmL);
-        } else {
-          if (hmR != 0ull) {
-            if ((int)refR < 0) {
-              leaf_test(refR & 0x7fffffffu, hmR);
-              if (openMask == 0ull) return;
-            } else {   // the right child waits
-              ldsWave[sp * kPacketEntry + 0] = (int)refR;
-              ldsWave[sp * kPacketEntry + 1] = (int)(uint32_t)hmR;
-              ldsWave[sp * kPacketEntry + 2] = (int)(uint32_t)(hmR >> 32);
-              sp++;
-            }
-          }
-          cur = refL; mask = hmL;
-          continue;
-        }
-      }
-      if (hmR != 0ull) {
-        if ((int)refR < 0) {
-          leaf_test(refR & 0x7fffffffu, hmR);
-        } else {
-          if (openMask == 0ull) return;
-          cur = refR; mask = hmR;
-          continue;
-        }
-      }
-      if (openMask == 0ull || sp == 0) return;   // every lane has its occluder, or nothing is left to visit
-      sp--;
-      cur = (uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 0]);
-      mask = (u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 1]) |
-             ((u64)(uint32_t)__builtin_amdgcn_readfirstlane(ldsWave[sp * kPacketEntry + 2]) << 32);
-    }
-  };
-  walk();
-  pl.hitType = ((openMask >> lane) & 1ull) != 0ull ? pl.hitType : 1;
+// Which waves walk as a packet: every ray finite (lt_retree.hpp) and small enough that no product of the conservative test can
+// overflow (lt_walk_asm.hpp: |origin| < 2^40, |1 / direction| < 2^60; the scene's bounds are below 2^40 or it has no own tree).
+__device__ __forceinline__ bool packet_ray_ok(const Ray& ray, float ix, float iy, float iz) {
+  return __builtin_fabsf(ix) < 0x1p+60f && __builtin_fabsf(iy) < 0x1p+60f && __builtin_fabsf(iz) < 0x1p+60f &&
+         __builtin_fabsf(ray.o.x) < 0x1p+40f && __builtin_fabsf(ray.o.y) < 0x1p+40f && __builtin_fabsf(ray.o.z) < 0x1p+40f;
 }
 
 // Camera rays: packet traversal when the wave qualifies, the per-lane traversal otherwise.
@@ -901,22 +789,22 @@ __device__ inline void traverse_camera(const SceneDev& sc, const Ray& ray, Hit& 
 #else
   constexpr bool kPackets = false;
 #endif
-  if (kPackets && __all(finite) && uniformSigns) {
+  // (the counting kernels walk the caller's tree as a packet, one node per step, lane masks on the stack: every lane's node and
+  // triangle counts are those of its own reference traversal; the others need the backend's own tree)
+  if (kPackets && __all(finite) && uniformSigns && (STATS || (sc.rank8 != nullptr && __all(packet_ray_ok(ray, ix, iy, iz))))) {
     if (STATS) c.rays++;
-    // two nodes per iteration from the child-pair records; the counting kernels keep the one-node walk, whose stack entries
-    // need no leaf counts
     if (STATS) traverse_packet<PROGRAM, STATS>(sc, ray, ix, iy, iz, bx != 0ull, by != 0ull, bz != 0ull, pl, st.lds - __lane_id(), c);
     else {
       int* const row = st.lds - __lane_id();
       switch ((bx != 0ull ? 1 : 0) | (by != 0ull ? 2 : 0) | (bz != 0ull ? 4 : 0)) {   // one specialisation per sign octant
-        case 0: traverse_packet_pairs<PROGRAM, 0>(sc, ray, ix, iy, iz, pl, row); break;
-        case 1: traverse_packet_pairs<PROGRAM, 1>(sc, ray, ix, iy, iz, pl, row); break;
-        case 2: traverse_packet_pairs<PROGRAM, 2>(sc, ray, ix, iy, iz, pl, row); break;
-        case 3: traverse_packet_pairs<PROGRAM, 3>(sc, ray, ix, iy, iz, pl, row); break;
-        case 4: traverse_packet_pairs<PROGRAM, 4>(sc, ray, ix, iy, iz, pl, row); break;
-        case 5: traverse_packet_pairs<PROGRAM, 5>(sc, ray, ix, iy, iz, pl, row); break;
-        case 6: traverse_packet_pairs<PROGRAM, 6>(sc, ray, ix, iy, iz, pl, row); break;
-        default: traverse_packet_pairs<PROGRAM, 7>(sc, ray, ix, iy, iz, pl, row); break;
+        case 0: packet_walk<PROGRAM, 0, false>(sc, ray, ix, iy, iz, -1, pl, row); break;
+        case 1: packet_walk<PROGRAM, 1, false>(sc, ray, ix, iy, iz, -1, pl, row); break;
+        case 2: packet_walk<PROGRAM, 2, false>(sc, ray, ix, iy, iz, -1, pl, row); break;
+        case 3: packet_walk<PROGRAM, 3, false>(sc, ray, ix, iy, iz, -1, pl, row); break;
+        case 4: packet_walk<PROGRAM, 4, false>(sc, ray, ix, iy, iz, -1, pl, row); break;
+        case 5: packet_walk<PROGRAM, 5, false>(sc, ray, ix, iy, iz, -1, pl, row); break;
+        case 6: packet_walk<PROGRAM, 6, false>(sc, ray, ix, iy, iz, -1, pl, row); break;
+        default: packet_walk<PROGRAM, 7, false>(sc, ray, ix, iy, iz, -1, pl, row); break;
       }
     }
   } else {
@@ -937,7 +825,8 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
   if (__all(finite)) {
     // (not in the global-illumination programs: most of their shadow rays start at bounce hits and are incoherent, and the
     // extra walks cost their register-heavy kernels a third of their speed on small scenes)
-    bool asPacket = ANYHIT && !DEEP && PROGRAM != kGI && PROGRAM != kGI25 && sc.shadowPackets != 0u;
+    bool asPacket = ANYHIT && !DEEP && PROGRAM != kGI && PROGRAM != kGI25 && sc.shadowPackets != 0u && sc.rank8 != nullptr &&
+                    __all(packet_ray_ok(ray, ix, iy, iz));
     if (asPacket && sc.shadowPackets == 2u) {   // per wavefront: are these 64 rays one bundle?
       auto first = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
       const float rx = first(ray.o.x), ry = first(ray.o.y), rz = first(ray.o.z);
@@ -947,24 +836,22 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
     if (asPacket) {
       int* const row = st.lds - __lane_id();
       const int ign = useIgnore ? ignore : -1;
-#ifndef LT_NO_SHADOW_OCTANTS   // (waves whose shadow rays share their direction signs: slab test without min / max, +1.9 % on the wall)
       const unsigned long long all = __builtin_amdgcn_ballot_w64(true), bx = __builtin_amdgcn_ballot_w64(ix < 0.0f),
                                by = __builtin_amdgcn_ballot_w64(iy < 0.0f), bz = __builtin_amdgcn_ballot_w64(iz < 0.0f);
       if ((bx == 0ull || bx == all) && (by == 0ull || by == all) && (bz == 0ull || bz == all)) {
         switch ((bx != 0ull ? 1 : 0) | (by != 0ull ? 2 : 0) | (bz != 0ull ? 4 : 0)) {
-          case 0: traverse_packet_pairs_anyhit<PROGRAM, 0>(sc, ray, ix, iy, iz, ign, pl, row); return;
-          case 1: traverse_packet_pairs_anyhit<PROGRAM, 1>(sc, ray, ix, iy, iz, ign, pl, row); return;
-          case 2: traverse_packet_pairs_anyhit<PROGRAM, 2>(sc, ray, ix, iy, iz, ign, pl, row); return;
-          case 3: traverse_packet_pairs_anyhit<PROGRAM, 3>(sc, ray, ix, iy, iz, ign, pl, row); return;
-          case 4: traverse_packet_pairs_anyhit<PROGRAM, 4>(sc, ray, ix, iy, iz, ign, pl, row); return;
-          case 5: traverse_packet_pairs_anyhit<PROGRAM, 5>(sc, ray, ix, iy, iz, ign, pl, row); return;
-          case 6: traverse_packet_pairs_anyhit<PROGRAM, 6>(sc, ray, ix, iy, iz, ign, pl, row); return;
-          default: traverse_packet_pairs_anyhit<PROGRAM, 7>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 0: packet_walk<PROGRAM, 0, true>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 1: packet_walk<PROGRAM, 1, true>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 2: packet_walk<PROGRAM, 2, true>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 3: packet_walk<PROGRAM, 3, true>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 4: packet_walk<PROGRAM, 4, true>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 5: packet_walk<PROGRAM, 5, true>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          case 6: packet_walk<PROGRAM, 6, true>(sc, ray, ix, iy, iz, ign, pl, row); return;
+          default: packet_walk<PROGRAM, 7, true>(sc, ray, ix, iy, iz, ign, pl, row); return;
         }
       }
-#endif
-      traverse_packet_pairs_anyhit<PROGRAM>(sc, ray, ix, iy, iz, ign, pl, row);
-      return;
+      // (a wave whose rays do not share an octant walks per lane: the sign-generic C++ form of the packet walk costs the
+      // 1 M-triangle frame 6 %, 21.3 against 20.0 ms)
     }
     if constexpr (!STATS && !LDSSCENE) {
       if (sc.rank8 != nullptr) {   // (the scene has a tree of the backend's own: lt_hip_set_scene)

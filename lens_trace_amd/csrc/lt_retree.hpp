@@ -50,6 +50,8 @@ inline int ceil_log2(uint32_t x) {
 // Reachable leaves of the caller's tree in its own pre-order, or false when the boxes do not nest (or hold a NaN).
 inline bool collect_leaves(const Node* nd, uint32_t n_nodes, std::vector<uint32_t>& leaves) {
   leaves.clear();
+  for (int a = 0; a < 3; a++)   // every box lies inside the root's: all bounds below 2^40 (the packet walks' conservative test, lt_walk_asm.hpp)
+    if (!(nd[0].lo[a] > -0x1p+40f && nd[0].hi[a] < 0x1p+40f && nd[0].lo[a] <= nd[0].hi[a])) return false;
   std::vector<uint32_t> stack{0u};
   while (!stack.empty()) {
     const uint32_t i = stack.back();
@@ -188,6 +190,33 @@ inline int build_range(const Node* nd, const float* centroid, std::vector<uint32
     work.push_back({r.start, mid, r.node + 1, r.depth + 1});
   }
   return height;
+}
+
+// The caller's own hierarchy, re-emitted in pre-order without its unreachable nodes (LT_RETREE=0: same walks, the caller's
+// splits).  Returns the height or -1 as build() does.
+inline int copy(const void* nodes, uint32_t n_nodes, int maxHeight, std::vector<Node>& out) {
+  const Node* nd = reinterpret_cast<const Node*>(nodes);
+  std::vector<uint32_t> leaves;
+  if (!collect_leaves(nd, n_nodes, leaves) || leaves.size() < 2) return -1;
+  if ((uint64_t)leaves.size() * 2 - 1 > 0x03ffffffull) return -1;
+  out.assign(2 * leaves.size() - 1, Node{});
+  struct Item { uint32_t src, parent; int depth; bool right; };
+  std::vector<Item> stack{{0u, 0xffffffffu, 0, false}};
+  uint32_t next = 0;
+  int height = 0;
+  while (!stack.empty()) {
+    const Item it = stack.back();
+    stack.pop_back();
+    const uint32_t at = next++;
+    out[at] = nd[it.src];
+    if (it.right) out[it.parent].off = (int32_t)at;
+    height = std::max(height, it.depth);
+    if (nd[it.src].cnt == 0) {
+      stack.push_back({(uint32_t)nd[it.src].off, at, it.depth + 1, true});
+      stack.push_back({it.src + 1, at, it.depth + 1, false});
+    }
+  }
+  return height <= maxHeight ? height : -1;
 }
 
 // out: 2 * leaves - 1 nodes.  Returns the height (interior ancestors of the deepest leaf), or -1 when no tree is built (boxes do

@@ -1,61 +1,69 @@
-// lt_walk_asm.hpp -- the packet walks below the root node, hand-written for gfx950 (CDNA4).
+// lt_walk_asm.hpp -- the packet walks over the backend's own tree, hand-written for gfx950 (CDNA4).
 //
-// The packet walks (lt_device.hpp: traverse_packet_pairs for camera rays, traverse_packet_pairs_anyhit for shadow rays) were
-// bound by SCALAR instruction issue as hipcc compiled them: rocprofv3 on the bench workload showed 0.75 scalar instructions
-// per CU-cycle against 0.62 of the VALU peak (profiles/r2/before_asm_issue_profile.json).  hipcc turns their wave-uniform,
-// multi-exit loops into a flag-driven state machine (structurised control flow: s_mov -1 / s_andn2 exec / s_cbranch_vccnz
-// chains, a loop-exit selector register, copies of every loop-carried mask and of the whole hit payload at each join): 25-30
-// scalar and ~10 wasted vector instructions per visited pair of nodes, where the algorithm needs about a dozen scalar ones.
-// This file is that dozen:
+// A packet = the 64 rays of a wavefront (an 8x8 pixel square's camera rays, or the shadow rays that leave its hit points), all
+// finite, all in one direction-sign octant.  The wave walks the tree ONCE, node data arriving through scalar loads, each lane
+// running the same slab test against its own ray.  What makes that exact is in lt_retree.hpp: over a tree whose boxes nest, a
+// finite ray reaches a leaf of the reference's traversal iff it passes the slab test of the leaf's OWN box, in whatever order
+// and through whatever enclosing boxes the candidates are enumerated.  So here
 //
-//   * one `s_load_dwordx16` per interior node brings the 64-byte child-pair record (lt_pair_kernel) into SGPRs;
-//   * the wave's lane mask of the node becomes EXEC for the two slab tests, so each test ends in ONE `v_cmp_ge_f32` whose
-//     SGPR-pair result already is "lanes of this node that hit the child" -- no s_and with the node's mask -- and the
-//     reference's two conditions `tEnter <= tExit && tExit > 0` (acc.cl:113-130, in box_mask<NEG>'s octant form) fold into
-//     `tExit >= max(tEnter, 0x00000001)`: the smallest positive float (denormals are kept: .amdhsa_float_denorm_mode_32 3)
-//     stands for "> 0", exact for every non-NaN input, and a packet is only formed from rays that cannot produce a NaN
-//     (traverse_camera / traverse: all origins and inverse directions finite);
-//   * branches test SCC straight from the mask arithmetic; the wave-uniform stack (child reference + 64-bit lane mask per
-//     entry, 16 bytes apart in the wave's LDS) is written / read with three ds_*_b32 of identical data per lane;
-//   * the triangle test (acc.cl:72-111 on the re-tiled 48-byte triangle: cross = fma(a, b, -(c * d)), dot = fma chain + the
-//     `w` terms, IEEE 1 / det by the div_scale / rcp / fma / div_fmas / div_fixup sequence hipcc emits for `1.0f / x` -- or,
-//     for the as-shipped math flavour (operand `fast`), the 2.5-ulp form the reference's NULL build options give it -- each
-//     reject written as the reference's negated compare) runs with EXEC = the lanes that reached the leaf, and every test
-//     NARROWS EXEC (v_cmpx): what is left of EXEC at the end is the mask of lanes that accept the hit;
+//   * interior nodes are tested CONSERVATIVELY and cheaply: a child-pair record (lt_own_pair_kernel, 64 bytes, one
+//     s_load_dwordx16) holds the two children's boxes pushed outwards by 2^-21 of each bound, and the test is
+//         tNear = max_a fma(near'_a, inv_a, -p_a),  tFar = min_a fma(far'_a, inv_a, -p_a),  tFar + M >= max(tNear, 0+)
+//     with p_a = fl(o_a * inv_a) and M = 2^-19 * max|p_a| + 2^-140 per lane: 11 vector instructions per box instead of the 16 of
+//     the reference's (bound - o) * inv form, and it accepts whenever that form does (proof below) -- a box entered needlessly
+//     costs a few instructions, a box skipped wrongly would cost a pixel;
+//   * a leaf gets the reference's own test: its record (the leaf's slot of the same array) carries the leaf's box bit for bit,
+//     the re-tiled triangle and the primitive offset; the slab test (acc.cl:113-130 in octant form: tExit >= max(tEnter, 0+),
+//     0+ = the smallest positive float, exact for every non-NaN input) and the triangle test (acc.cl:72-111: cross =
+//     fma(a, b, -(c * d)), dot = fma chain + the `w` terms, IEEE 1 / det by the div_scale / rcp / fma / div_fmas / div_fixup
+//     sequence hipcc emits for `1.0f / x` -- or, for the as-shipped math flavour (operand `fast`), the 2.5-ulp form the
+//     reference's NULL build options give it) run with EXEC narrowed test by test (v_cmpx): what is left of EXEC at the end is
+//     the mask of lanes that accept the hit;
+//   * no order, no lane masks: every popped node is tested by every lane still in the walk (a lane outside the node's parent
+//     cannot be inside the node), so a stack entry is ONE dword -- a node index, bit 31 set for a leaf -- and the stack is one
+//     VGPR whose 64 lanes are its 64 slots (v_writelane / v_readlane with the stack pointer in M0): no LDS, no latency.  Pushes
+//     are branch-free: write the child at the top, then add "some lane hit it" (SCC of s_cmp_lg_u64) to the pointer.  Depth:
+//     at most two waiting entries per level plus four at the frontier, 2 * height + 2 <= 62 (the build caps the height at 30);
+//   * two interior nodes per iteration when the stack holds two: their records are fetched together, halving the number of
+//     dependent memory round trips, which is what this walk waits for (scalar-cache hit rate 23 %, L2 61 % on the 1 M-triangle
+//     scene);
+//   * closest-hit walks (camera rays) keep the payload (t, u, v, primitive, hitType: RayPayload, acc.cl:55-61) in five VGPRs;
+//     two accepted hits with bit-equal t are settled by the reference's leaf order (SceneDev::rank8); any-hit walks (shadow
+//     rays: their callers read hitType only) drop a lane from `open` at its first accepted hit and end when `open` is empty.
+//
+// The conservative test accepts whenever the reference's does.  Per axis, with i = inv_a > 0 (the other sign mirrors), near
+// bound lo, lo' <= lo - 6u|lo| (u = 2^-24; lt_own_pair_kernel subtracts 2^-21 |lo| and steps one float further down), all
+// magnitudes below 2^101 so nothing overflows (|o|, |bound| < 2^40, |inv| < 2^60: checked per wave / per scene):
+//     reference: tN = fl(fl(lo - o) i)            >= (lo - o) i - 2u (|lo| + |o|) i          (two roundings)
+//     here:      tN' = fl(lo' i - p), p = fl(o i)  <= (lo - o) i - 6u |lo| i + u |o i| + u (|lo'| i + |p|)   (p's rounding, fma's)
+//                                                  <= (lo - o) i - 4u |lo| i + 2.01 u |o i|
+//  so tN' <= tN + 4.01 u |o i| <= tN + M/2 (M >= 32 u max|p|), and symmetrically tF' >= tF - M/2 for the far bound; hence
+//  tF >= max(tN, 0+) implies tF' + M >= tF + M/2 >= max(tN', 0+).  (Gradual underflow adds at most 2^-148 per operation: the
+//  2^-140 in M.)
 //
 // Hazards (none of the instructions below needs a manually inserted wait state on gfx950 beyond these): v_div_fmas reads the
 // VCC written by the second v_div_scale four VALU instructions earlier; v_rcp's result is first read three instructions
-// later; SGPRs written by VALU (v_cmp, v_readfirstlane) are read by SALU / as SMEM offsets only (no VMEM, no v_readlane lane
-// select, no DPP); DS results are waited for with s_waitcnt lgkmcnt(0) before v_readfirstlane; an SMEM instruction reads its
-// address operands at issue, so the offset register is reused right after.  EXEC is saved on entry and restored on exit.
+// later; SGPRs written by VALU (v_cmp, v_readlane) are read by SALU / as SMEM offsets only; M0 (the lane select of
+// v_readlane / v_writelane) is written by SALU only; an SMEM instruction reads its address operands at issue, so the offset
+// register is reused right after.  EXEC and M0 are saved on entry and restored on exit.
 #pragma once
 
 namespace lt {
 
 typedef unsigned long long lt_u64;
 
-// ---- fixed scalar registers (all clobbered; operands live elsewhere) -----------------------------------------------------
-// child-pair record s[36:51] (lt_pair_kernel): a reference with bit 31 set is a leaf (0x80000000 | primitive offset), else an
-// interior node (index | split axis << 29)
-#define LT_R_REC "s[36:51]"
-#define LT_R_LMINX "s36"
-#define LT_R_LMINY "s37"
-#define LT_R_LMINZ "s38"
-#define LT_R_LMAXX "s39"
-#define LT_R_LMAXY "s40"
-#define LT_R_LMAXZ "s41"
-#define LT_R_REFL "s42"
-#define LT_R_RMINX "s44"
-#define LT_R_RMINY "s45"
-#define LT_R_RMINZ "s46"
-#define LT_R_RMAXX "s47"
-#define LT_R_RMAXY "s48"
-#define LT_R_RMAXZ "s49"
-#define LT_R_REFR "s50"
-// triangle (lt_retile_kernel): A, e1 = B - A, e2 = C - A -- in the record's registers: a record is dead once its two child
-// references and hit masks have been moved on (s32 / s33, the ABI's stack and frame pointers, are never touched)
-#define LT_R_TRI8 "s[36:43]"
-#define LT_R_TRI4 "s[44:47]"
+// ---- fixed scalar registers (all clobbered; operands live elsewhere; s32 / s33, the ABI's stack and frame pointers, are never
+// touched) -------------------------------------------------------------------------------------------------------------------
+// record 0 s[36:51], record 1 s[52:67]: interior node = [left box lo hi, reference, -][right box lo hi, reference, -];
+// a reference with bit 31 set is a leaf (0x80000000 | node index), else an interior node's index
+#define LT_R_REC0 "s[36:51]"
+#define LT_R_REC1 "s[52:67]"
+#define LT_R_REF0L "s42"
+#define LT_R_REF0R "s50"
+#define LT_R_REF1L "s58"
+#define LT_R_REF1R "s66"
+// leaf record, in record 0's registers: triangle A, e1 = B - A, e2 = C - A (lt_retile_kernel's arithmetic), the leaf's box, the
+// primitive offset
 #define LT_R_AX "s36"
 #define LT_R_AY "s37"
 #define LT_R_AZ "s38"
@@ -65,102 +73,89 @@ typedef unsigned long long lt_u64;
 #define LT_R_E2X "s42"
 #define LT_R_E2Y "s43"
 #define LT_R_E2Z "s44"
-#define LT_R_TMPM "s[52:53]"   /* scratch mask / popped mask */
-#define LT_R_TMPLO "s52"
-#define LT_R_TMPHI "s53"
-#define LT_R_PRIM "s54"        /* scratch; in the triangle test: the primitive offset */
-#define LT_R_LEAF "s55"        /* pending leaf reference / scratch */
-#define LT_R_EXEC "s[56:57]"   /* EXEC on entry */
-#define LT_R_HML "s[58:59]"
-#define LT_R_HMLLO "s58"
-#define LT_R_HMLHI "s59"
-#define LT_R_HMR "s[60:61]"
-#define LT_R_HMRLO "s60"
-#define LT_R_HMRHI "s61"
-#define LT_R_LEAFM "s[62:63]"  /* lanes of the pending leaf */
+#define LT_R_PRIM "s51"
+// (a kernel that keeps eight waves per SIMD owns s0 .. s71: everything below fits under that)
+#define LT_R_HML "s[68:69]"    /* lanes that hit the child just tested; in the leaf test: v_cmpx destination, tie masks */
+#define LT_R_HMR "s[70:71]"
+#define LT_R_EXEC "s[16:17]"   /* EXEC on entry */
+#define LT_R_TMPM "s[18:19]"
+#define LT_R_TMPLO "s18"
+#define LT_R_TMPHI "s19"
+#define LT_R_CUR "s20"
+#define LT_R_CUR2 "s21"
+#define LT_R_M0 "s22"          /* M0 on entry */
+#define LT_R_LEAF "s23"        /* scratch */
 #define LT_ASM_CLOBBERS                                                                                                         \
   "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", \
-  "s60", "s61", "s62", "s63", "vcc", "scc", "memory"
+  "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23",                               \
+  "vcc", "scc", "memory"
 
-// slab test of one child: near / far plane registers chosen by the wave's direction-sign octant; result in the SGPR pair OUT
-#define LT_ASM_BOX(NX, NY, NZ, FX, FY, FZ, OUT)      \
-  "v_sub_f32_e32 %[t0], " NX ", %[ox]\n"            \
-  "v_sub_f32_e32 %[t1], " NY ", %[oy]\n"            \
-  "v_sub_f32_e32 %[t2], " NZ ", %[oz]\n"            \
-  "v_mul_f32_e32 %[t0], %[t0], %[ix]\n"             \
-  "v_mul_f32_e32 %[t1], %[t1], %[iy]\n"             \
-  "v_mul_f32_e32 %[t2], %[t2], %[iz]\n"             \
-  "v_max3_f32 %[t0], %[t0], %[t1], %[t2]\n"         \
-  "v_sub_f32_e32 %[t1], " FX ", %[ox]\n"            \
-  "v_sub_f32_e32 %[t2], " FY ", %[oy]\n"            \
-  "v_sub_f32_e32 %[t3], " FZ ", %[oz]\n"            \
-  "v_mul_f32_e32 %[t1], %[t1], %[ix]\n"             \
-  "v_mul_f32_e32 %[t2], %[t2], %[iy]\n"             \
-  "v_mul_f32_e32 %[t3], %[t3], %[iz]\n"             \
-  "v_min3_f32 %[t1], %[t1], %[t2], %[t3]\n"         \
-  "v_max_f32_e32 %[t0], 1, %[t0]\n"                 \
+// conservative slab test of one child of an interior record (see the head of the file): 11 instructions
+#define LT_ASM_BOXC(NX, NY, NZ, FX, FY, FZ, OUT)       \
+  "v_fma_f32 %[t0], " NX ", %[ix], -%[px]\n"          \
+  "v_fma_f32 %[t1], " NY ", %[iy], -%[py]\n"          \
+  "v_fma_f32 %[t2], " NZ ", %[iz], -%[pz]\n"          \
+  "v_max3_f32 %[t0], %[t0], %[t1], %[t2]\n"           \
+  "v_fma_f32 %[t1], " FX ", %[ix], -%[px]\n"          \
+  "v_fma_f32 %[t2], " FY ", %[iy], -%[py]\n"          \
+  "v_fma_f32 %[t3], " FZ ", %[iz], -%[pz]\n"          \
+  "v_min3_f32 %[t1], %[t1], %[t2], %[t3]\n"           \
+  "v_add_f32_e32 %[t1], %[t1], %[mg]\n"               \
+  "v_max_f32_e32 %[t0], 1, %[t0]\n"                   \
   "v_cmp_ge_f32_e64 " OUT ", %[t1], %[t0]\n"
 
-// the two children's tests for the octant NEG (bit a set = direction component a negative: the near plane is the box's max)
-#define LT_ASM_BOXES_0 LT_ASM_BOX(LT_R_LMINX, LT_R_LMINY, LT_R_LMINZ, LT_R_LMAXX, LT_R_LMAXY, LT_R_LMAXZ, LT_R_HML) LT_ASM_BOX(LT_R_RMINX, LT_R_RMINY, LT_R_RMINZ, LT_R_RMAXX, LT_R_RMAXY, LT_R_RMAXZ, LT_R_HMR)
-#define LT_ASM_BOXES_1 LT_ASM_BOX(LT_R_LMAXX, LT_R_LMINY, LT_R_LMINZ, LT_R_LMINX, LT_R_LMAXY, LT_R_LMAXZ, LT_R_HML) LT_ASM_BOX(LT_R_RMAXX, LT_R_RMINY, LT_R_RMINZ, LT_R_RMINX, LT_R_RMAXY, LT_R_RMAXZ, LT_R_HMR)
-#define LT_ASM_BOXES_2 LT_ASM_BOX(LT_R_LMINX, LT_R_LMAXY, LT_R_LMINZ, LT_R_LMAXX, LT_R_LMINY, LT_R_LMAXZ, LT_R_HML) LT_ASM_BOX(LT_R_RMINX, LT_R_RMAXY, LT_R_RMINZ, LT_R_RMAXX, LT_R_RMINY, LT_R_RMAXZ, LT_R_HMR)
-#define LT_ASM_BOXES_3 LT_ASM_BOX(LT_R_LMAXX, LT_R_LMAXY, LT_R_LMINZ, LT_R_LMINX, LT_R_LMINY, LT_R_LMAXZ, LT_R_HML) LT_ASM_BOX(LT_R_RMAXX, LT_R_RMAXY, LT_R_RMINZ, LT_R_RMINX, LT_R_RMINY, LT_R_RMAXZ, LT_R_HMR)
-#define LT_ASM_BOXES_4 LT_ASM_BOX(LT_R_LMINX, LT_R_LMINY, LT_R_LMAXZ, LT_R_LMAXX, LT_R_LMAXY, LT_R_LMINZ, LT_R_HML) LT_ASM_BOX(LT_R_RMINX, LT_R_RMINY, LT_R_RMAXZ, LT_R_RMAXX, LT_R_RMAXY, LT_R_RMINZ, LT_R_HMR)
-#define LT_ASM_BOXES_5 LT_ASM_BOX(LT_R_LMAXX, LT_R_LMINY, LT_R_LMAXZ, LT_R_LMINX, LT_R_LMAXY, LT_R_LMINZ, LT_R_HML) LT_ASM_BOX(LT_R_RMAXX, LT_R_RMINY, LT_R_RMAXZ, LT_R_RMINX, LT_R_RMAXY, LT_R_RMINZ, LT_R_HMR)
-#define LT_ASM_BOXES_6 LT_ASM_BOX(LT_R_LMINX, LT_R_LMAXY, LT_R_LMAXZ, LT_R_LMAXX, LT_R_LMINY, LT_R_LMINZ, LT_R_HML) LT_ASM_BOX(LT_R_RMINX, LT_R_RMAXY, LT_R_RMAXZ, LT_R_RMAXX, LT_R_RMINY, LT_R_RMINZ, LT_R_HMR)
-#define LT_ASM_BOXES_7 LT_ASM_BOX(LT_R_LMAXX, LT_R_LMAXY, LT_R_LMAXZ, LT_R_LMINX, LT_R_LMINY, LT_R_LMINZ, LT_R_HML) LT_ASM_BOX(LT_R_RMAXX, LT_R_RMAXY, LT_R_RMAXZ, LT_R_RMINX, LT_R_RMINY, LT_R_RMINZ, LT_R_HMR)
+// the reference's slab test of a leaf's own box (acc.cl:113-130, octant form), narrowing EXEC to the lanes that pass
+#define LT_ASM_BOXX(NX, NY, NZ, FX, FY, FZ)            \
+  "v_sub_f32_e32 %[t0], " NX ", %[ox]\n"              \
+  "v_sub_f32_e32 %[t1], " NY ", %[oy]\n"              \
+  "v_sub_f32_e32 %[t2], " NZ ", %[oz]\n"              \
+  "v_mul_f32_e32 %[t0], %[t0], %[ix]\n"               \
+  "v_mul_f32_e32 %[t1], %[t1], %[iy]\n"               \
+  "v_mul_f32_e32 %[t2], %[t2], %[iz]\n"               \
+  "v_max3_f32 %[t0], %[t0], %[t1], %[t2]\n"           \
+  "v_sub_f32_e32 %[t1], " FX ", %[ox]\n"              \
+  "v_sub_f32_e32 %[t2], " FY ", %[oy]\n"              \
+  "v_sub_f32_e32 %[t3], " FZ ", %[oz]\n"              \
+  "v_mul_f32_e32 %[t1], %[t1], %[ix]\n"               \
+  "v_mul_f32_e32 %[t2], %[t2], %[iy]\n"               \
+  "v_mul_f32_e32 %[t3], %[t3], %[iz]\n"               \
+  "v_min3_f32 %[t1], %[t1], %[t2], %[t3]\n"           \
+  "v_max_f32_e32 %[t0], 1, %[t0]\n"                   \
+  "v_cmpx_ge_f32_e64 " LT_R_HML ", %[t1], %[t0]\n"
 
-// push (reference REF, lane mask LO:HI) on the wave-uniform stack
-#define LT_ASM_PUSH(REF, LO, HI)                    \
-  "v_lshl_add_u32 %[t0], %[sp], 4, %[lds]\n"        \
-  "v_mov_b32_e32 %[t1], " REF "\n"                  \
-  "v_mov_b32_e32 %[t2], " LO "\n"                   \
-  "v_mov_b32_e32 %[t3], " HI "\n"                   \
-  "ds_write_b32 %[t0], %[t1]\n"                     \
-  "ds_write_b32 %[t0], %[t2] offset:4\n"            \
-  "ds_write_b32 %[t0], %[t3] offset:8\n"            \
-  "s_add_u32 %[sp], %[sp], 1\n"
+// Box register triples: record 0 left s36-38 / s39-41, right s44-46 / s47-49; record 1 left s52-54 / s55-57, right s60-62 /
+// s63-65; leaf box s45-47 / s48-50.
+#define LT_LOHI_0 "s36", "s37", "s38", "s39", "s40", "s41"
+#define LT_LOHI_1 "s44", "s45", "s46", "s47", "s48", "s49"
+#define LT_LOHI_2 "s52", "s53", "s54", "s55", "s56", "s57"
+#define LT_LOHI_3 "s60", "s61", "s62", "s63", "s64", "s65"
+#define LT_LOHI_LEAF "s45", "s46", "s47", "s48", "s49", "s50"
+// (lo.x lo.y lo.z hi.x hi.y hi.z) -> (near.x near.y near.z far.x far.y far.z) for the octant NEG: the near plane of axis a is the
+// box's max when direction component a is negative (bit a of NEG)
+#define LT_NF_0(LX, LY, LZ, HX, HY, HZ) LX, LY, LZ, HX, HY, HZ
+#define LT_NF_1(LX, LY, LZ, HX, HY, HZ) HX, LY, LZ, LX, HY, HZ
+#define LT_NF_2(LX, LY, LZ, HX, HY, HZ) LX, HY, LZ, HX, LY, HZ
+#define LT_NF_3(LX, LY, LZ, HX, HY, HZ) HX, HY, LZ, LX, LY, HZ
+#define LT_NF_4(LX, LY, LZ, HX, HY, HZ) LX, LY, HZ, HX, HY, LZ
+#define LT_NF_5(LX, LY, LZ, HX, HY, HZ) HX, LY, HZ, LX, HY, LZ
+#define LT_NF_6(LX, LY, LZ, HX, HY, HZ) LX, HY, HZ, HX, LY, LZ
+#define LT_NF_7(LX, LY, LZ, HX, HY, HZ) HX, HY, HZ, LX, LY, LZ
+#define LT_APPLY(M, ...) M(__VA_ARGS__)
+#define LT_ASM_BOXC_OUT(OUT, NX, NY, NZ, FX, FY, FZ) LT_ASM_BOXC(NX, NY, NZ, FX, FY, FZ, OUT)
+#define LT_BOXC_N(NF, LOHI, OUT) LT_APPLY(LT_ASM_BOXC_OUT, OUT, LT_APPLY(NF, LOHI))
+#define LT_BOXX_N(NF, LOHI) LT_APPLY(LT_ASM_BOXX, LT_APPLY(NF, LOHI))
 
-// Load the node record of `cur` and wait for it.
-#define LT_ASM_LOAD_NODE                                    \
-  "s_and_b32 " LT_R_PRIM ", %[cur], 0x1fffffff\n"          \
-  "s_lshl_b32 " LT_R_PRIM ", " LT_R_PRIM ", 6\n"           \
-  "s_load_dwordx16 " LT_R_REC ", %[pairs], " LT_R_PRIM "\n" \
-  "s_waitcnt lgkmcnt(0)\n"
-
-// pop the top entry: reference -> LT_R_LEAF, mask -> LT_R_TMPM (EXEC = the entry EXEC: every lane reads the same address)
-#define LT_ASM_POP_TOP                                      \
-  "s_mov_b64 exec, " LT_R_EXEC "\n"                         \
-  "s_sub_u32 %[sp], %[sp], 1\n"                             \
-  "v_lshl_add_u32 %[t0], %[sp], 4, %[lds]\n"                \
-  "ds_read_b32 %[t1], %[t0]\n"                              \
-  "ds_read_b32 %[t2], %[t0] offset:4\n"                     \
-  "ds_read_b32 %[t3], %[t0] offset:8\n"                     \
-  "s_waitcnt lgkmcnt(0)\n"                                  \
-  "v_readfirstlane_b32 " LT_R_LEAF ", %[t1]\n"              \
-  "v_readfirstlane_b32 " LT_R_TMPLO ", %[t2]\n"             \
-  "v_readfirstlane_b32 " LT_R_TMPHI ", %[t3]\n"
-
-// Start of a triangle test: LT_R_LEAF = the leaf's reference, LT_R_LEAFM = its lanes, %[cur] = the interior node to go to
-// afterwards or -1 = "pop".  Ends with EXEC = the leaf's lanes; LT_ASM_TRI_PART1 waits for the loads.
-// (Issuing the NEXT node's record load beside the triangle's -- `cur`, or the peeked top of the stack, into registers of its
-// own -- so that the node-to-node load latency hides behind the test was built and measured: 28.45 against 28.55 ms per
-// 16-sample 4K frame, i.e. nothing.  Eight waves per SIMD already cover that latency; the walk is bound by instruction issue.)
-#define LT_ASM_LEAF_PROLOGUE                                                                                                    \
-  ".Lleaf%=:\n"                                                                                                                 \
-  "s_and_b32 " LT_R_PRIM ", " LT_R_LEAF ", 0x7fffffff\n"                                                                         \
-  "s_mul_i32 " LT_R_TMPLO ", " LT_R_PRIM ", 48\n"                                                                                \
-  "s_load_dwordx8 " LT_R_TRI8 ", %[tris], " LT_R_TMPLO "\n"                                                                      \
-  "s_load_dwordx4 " LT_R_TRI4 ", %[tris], " LT_R_TMPLO " offset:0x20\n"                                                          \
-  "s_mov_b64 exec, " LT_R_LEAFM "\n"
+// branch-free push of a child reference: written at the top, kept iff some lane hit the child
+#define LT_ASM_PUSH(REF, HM)                        \
+  "v_writelane_b32 %[stk], " REF ", m0\n"           \
+  "s_cmp_lg_u64 " HM ", 0\n"                        \
+  "s_addc_u32 m0, m0, 0\n"
 
 // det, 1 / det, u (EXEC narrowed by the det and u tests); leaves: t0 = invDet, t1 = u, t7 t8 t9 = tvec
 #define LT_ASM_TRI_PART1                                                                                                        \
-  "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
   "v_mul_f32_e64 %[t4], %[dz], -" LT_R_E2Y "\n"     /* pvec = cross(d, e2) */                                                   \
-  "v_fmac_f32_e32 %[t4], " LT_R_E2Z ", %[dy]\n"                                                                                 \
   "v_mul_f32_e64 %[t5], %[dx], -" LT_R_E2Z "\n"                                                                                 \
+  "v_fmac_f32_e32 %[t4], " LT_R_E2Z ", %[dy]\n"                                                                                 \
   "v_fmac_f32_e32 %[t5], " LT_R_E2X ", %[dz]\n"                                                                                 \
   "v_mul_f32_e64 %[t6], %[dy], -" LT_R_E2X "\n"                                                                                 \
   "v_mul_f32_e32 %[t0], " LT_R_E1X ", %[t4]\n"                                                                                  \
@@ -227,208 +222,14 @@ typedef unsigned long long lt_u64;
   "v_cmpx_nlt_f32_e64 " LT_R_HML ", 1.0, %[t10]\n"  /* !(u + v > 1) */                                                          \
   "v_mul_f32_e32 %[t3], %[t3], %[t0]\n"             /* t */
 
-// after a triangle test: on to node `cur`, or pop
-#define LT_ASM_LEAF_EPILOGUE                                \
-  ".LleafEnd%=:\n"                                          \
-  "s_cmp_eq_u32 %[cur], -1\n"                               \
-  "s_cbranch_scc0 .Ltop%=\n"                                \
-  "s_branch .Lpop%=\n"
-
-// ---------------------------------------------------------------------------------------------------------------- any-hit
-// Order-free walk for shadow rays (lt_device.hpp, traverse_packet_pairs_anyhit): a leaf is tested as soon as it is met (before
-// descending into a sibling subtree), the other hit child is entered next or pushed.  `open` = lanes still looking for an
-// occluder; nodes none of them reaches are skipped; the walk ends when `open` is empty or the stack is.
-#define LT_ASM_ANYHIT_WALK(BOXES)                                                                                               \
-  "s_mov_b64 " LT_R_EXEC ", exec\n"                                                                                             \
-  ".Ltop%=:\n"                                                                                                                  \
-  LT_ASM_LOAD_NODE                                                                                                              \
-  "s_and_b64 " LT_R_TMPM ", %[mask], %[open]\n"     /* lanes of this node that still look: SCC = any */                          \
-  "s_cbranch_scc0 .Lpop%=\n"                                                                                                    \
-  "s_mov_b64 exec, " LT_R_TMPM "\n"                                                                                             \
-  BOXES                                                                                                                         \
-  "s_or_b64 " LT_R_TMPM ", " LT_R_HML ", " LT_R_HMR "\n"                                                                         \
-  "s_cbranch_scc0 .Lpop%=\n"                        /* both children missed */                                                  \
-  "s_cmp_lg_u64 " LT_R_HML ", 0\n"                                                                                              \
-  "s_cbranch_scc0 .LonlyR%=\n"                                                                                                  \
-  "s_cmp_lt_i32 " LT_R_REFL ", 0\n"                                                                                             \
-  "s_cbranch_scc1 .LleafL%=\n"                                                                                                  \
-  /* left child: interior, hit */                                                                                               \
-  "s_cmp_lg_u64 " LT_R_HMR ", 0\n"                                                                                              \
-  "s_cbranch_scc0 .LdescL%=\n"                                                                                                  \
-  "s_cmp_lt_i32 " LT_R_REFR ", 0\n"                                                                                             \
-  "s_cbranch_scc1 .LevR_thenL%=\n"                                                                                              \
-  LT_ASM_PUSH(LT_R_REFR, LT_R_HMRLO, LT_R_HMRHI)    /* right child: interior, hit too: it waits */                              \
-  ".LdescL%=:\n"                                                                                                                \
-  "s_mov_b32 %[cur], " LT_R_REFL "\n"                                                                                           \
-  "s_mov_b64 %[mask], " LT_R_HML "\n"                                                                                           \
-  "s_branch .Ltop%=\n"                                                                                                          \
-  ".LleafL%=:\n"                                    /* left child: a leaf some lane hit -> test it */                           \
-  "s_mov_b32 " LT_R_LEAF ", " LT_R_REFL "\n"                                                                                    \
-  "s_mov_b64 " LT_R_LEAFM ", " LT_R_HML "\n"                                                                                    \
-  "s_mov_b32 %[cur], -1\n"                                                                                                      \
-  "s_cmp_lg_u64 " LT_R_HMR ", 0\n"                                                                                              \
-  "s_cbranch_scc0 .Lleaf%=\n"                                                                                                   \
-  "s_cmp_lt_i32 " LT_R_REFR ", 0\n"                                                                                             \
-  "s_cbranch_scc1 .LpushR_leaf%=\n"                                                                                             \
-  "s_mov_b32 %[cur], " LT_R_REFR "\n"               /* then the right child (interior) */                                       \
-  "s_mov_b64 %[mask], " LT_R_HMR "\n"                                                                                           \
-  "s_branch .Lleaf%=\n"                                                                                                         \
-  ".LpushR_leaf%=:\n"                                                                                                           \
-  LT_ASM_PUSH(LT_R_REFR, LT_R_HMRLO, LT_R_HMRHI)    /* right child: a second leaf, comes back through the stack */              \
-  "s_branch .Lleaf%=\n"                                                                                                         \
-  ".LevR_thenL%=:\n"                                /* right leaf first (order is free), then into the left child */            \
-  "s_mov_b32 " LT_R_LEAF ", " LT_R_REFR "\n"                                                                                    \
-  "s_mov_b64 " LT_R_LEAFM ", " LT_R_HMR "\n"                                                                                    \
-  "s_mov_b32 %[cur], " LT_R_REFL "\n"                                                                                           \
-  "s_mov_b64 %[mask], " LT_R_HML "\n"                                                                                           \
-  "s_branch .Lleaf%=\n"                                                                                                         \
-  ".LonlyR%=:\n"                                                                                                                \
-  "s_cmp_lt_i32 " LT_R_REFR ", 0\n"                                                                                             \
-  "s_cbranch_scc1 .LevR_pop%=\n"                                                                                                \
-  "s_mov_b32 %[cur], " LT_R_REFR "\n"                                                                                           \
-  "s_mov_b64 %[mask], " LT_R_HMR "\n"                                                                                           \
-  "s_branch .Ltop%=\n"                                                                                                          \
-  ".LevR_pop%=:\n"                                                                                                              \
-  "s_mov_b32 " LT_R_LEAF ", " LT_R_REFR "\n"                                                                                    \
-  "s_mov_b64 " LT_R_LEAFM ", " LT_R_HMR "\n"                                                                                    \
-  "s_mov_b32 %[cur], -1\n"                                                                                                      \
-  "s_branch .Lleaf%=\n"                                                                                                         \
-  ".Lpop%=:\n"                                                                                                                  \
-  "s_cmp_eq_u32 %[sp], 0\n"                                                                                                     \
-  "s_cbranch_scc1 .Ldone%=\n"                                                                                                   \
-  LT_ASM_POP_TOP                                                                                                                \
-  "s_cmp_lt_i32 " LT_R_LEAF ", 0\n"                                                                                             \
-  "s_cbranch_scc1 .LpoppedLeaf%=\n"                                                                                             \
-  "s_mov_b32 %[cur], " LT_R_LEAF "\n"                                                                                           \
-  "s_mov_b64 %[mask], " LT_R_TMPM "\n"                                                                                          \
-  "s_branch .Ltop%=\n"                                                                                                          \
-  ".LpoppedLeaf%=:\n"                                                                                                           \
-  "s_and_b64 " LT_R_LEAFM ", " LT_R_TMPM ", %[open]\n" /* lanes of it that still look */                                        \
-  "s_cbranch_scc0 .Lpop%=\n"                                                                                                    \
-  "s_mov_b32 %[cur], -1\n"                                                                                                      \
-  LT_ASM_LEAF_PROLOGUE                                                                                                          \
-  "v_cmpx_ne_u32_e64 " LT_R_HML ", " LT_R_PRIM ", %[ign]\n" /* not the primitive the ray starts on (acc.cl:188) */              \
-  LT_ASM_TRI_PART1                                                                                                              \
-  LT_ASM_TRI_PART2                                                                                                              \
-  "v_cmpx_lt_f32_e64 " LT_R_HML ", %[t3], %[tmax]\n" /* t < payload.t: accepted */                                              \
-  "s_andn2_b64 %[open], %[open], exec\n"            /* those lanes are done; SCC = anyone still looking */                      \
-  "s_cbranch_scc0 .Ldone%=\n"                                                                                                   \
-  LT_ASM_LEAF_EPILOGUE                                                                                                          \
-  ".Ldone%=:\n"                                                                                                                 \
-  "s_mov_b64 exec, " LT_R_EXEC "\n"
-
-// The whole any-hit walk below the root: on return `open` holds the lanes that found no occluder.  NEG = the direction-sign
-// octant all rays of the wave share; eps = the program's triangle epsilon as the float the reference's double compare amounts
-// to (intersect_triangle_data).
-template <int NEG>
-__device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, const void* tris, float ox, float oy, float oz, float ix, float iy,
-                                                     float iz, float dx, float dy, float dz, float dw, float tmax, int ign, float eps,
-                                                     uint32_t fast, uint32_t lds, lt_u64 mask, lt_u64 open) {
-  uint32_t cur = 0u, sp = 0u;
-  float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
-#define LT_ANYHIT_INSTANCE(BOXES)                                                                                                        \
-  asm volatile(LT_ASM_ANYHIT_WALK(BOXES)                                                                                                 \
-               : [cur] "+s"(cur), [mask] "+s"(mask), [sp] "+s"(sp), [open] "+s"(open), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),    \
-                 [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9),         \
-                 [t10] "=&v"(t10)                                                                                                        \
-               : [pairs] "s"(pairs), [tris] "s"(tris), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), \
-                 [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [dw] "v"(dw), [tmax] "v"(tmax), [ign] "v"(ign), [eps] "s"(eps), [fast] "s"(fast), [lds] "v"(lds) \
-               : LT_ASM_CLOBBERS)
-  if constexpr (NEG == 0) LT_ANYHIT_INSTANCE(LT_ASM_BOXES_0);
-  else if constexpr (NEG == 1) LT_ANYHIT_INSTANCE(LT_ASM_BOXES_1);
-  else if constexpr (NEG == 2) LT_ANYHIT_INSTANCE(LT_ASM_BOXES_2);
-  else if constexpr (NEG == 3) LT_ANYHIT_INSTANCE(LT_ASM_BOXES_3);
-  else if constexpr (NEG == 4) LT_ANYHIT_INSTANCE(LT_ASM_BOXES_4);
-  else if constexpr (NEG == 5) LT_ANYHIT_INSTANCE(LT_ASM_BOXES_5);
-  else if constexpr (NEG == 6) LT_ANYHIT_INSTANCE(LT_ASM_BOXES_6);
-  else LT_ANYHIT_INSTANCE(LT_ASM_BOXES_7);
-#undef LT_ANYHIT_INSTANCE
-  return open;
-}
-
-// ------------------------------------------------------------------------------------------------------------ closest hit
-// The camera-ray walk (lt_device.hpp, traverse_packet_pairs): per lane the reference's order -- the near child's subtree (or
-// leaf) completely before the far child's, near = the child on the side the rays come from along the node's split axis
-// (acc.cl:150-160: dirIsNeg[node->axis]) -- so a far child that is hit while the near one is entered waits on the stack, and a
-// far LEAF behind a near leaf goes through the stack too (it is the top entry, popped at once).  The payload (t, u, v,
-// primitive, hitType: RayPayload, acc.cl:55-61) lives in five VGPRs and is overwritten under the EXEC the triangle test ends
-// with: the lanes whose `t < payload.t` held.
-//   visit(N = near, F = far): TAG makes the labels of the two instances distinct
-#define LT_ASM_VISIT(TAG, HMN, REFN, HMF, REFF, FLO, FHI)                                                                        \
-  "s_cmp_lg_u64 " HMN ", 0\n"                                                                                                   \
-  "s_cbranch_scc0 .LnMiss" TAG "%=\n"                                                                                           \
-  "s_cmp_lt_i32 " REFN ", 0\n"                                                                                                  \
-  "s_cbranch_scc1 .LnLeaf" TAG "%=\n"                                                                                           \
-  "s_cmp_lg_u64 " HMF ", 0\n"                       /* near: interior, hit */                                                   \
-  "s_cbranch_scc0 .Ldesc" TAG "%=\n"                                                                                            \
-  LT_ASM_PUSH(REFF, FLO, FHI)                       /* far child (leaf or interior) waits */                                    \
-  ".Ldesc" TAG "%=:\n"                                                                                                          \
-  "s_mov_b32 %[cur], " REFN "\n"                                                                                                \
-  "s_mov_b64 %[mask], " HMN "\n"                                                                                                \
-  "s_branch .Ltop%=\n"                                                                                                          \
-  ".LnLeaf" TAG "%=:\n"                             /* near: a leaf some lane hit -> test it now */                             \
-  "s_mov_b32 " LT_R_LEAF ", " REFN "\n"                                                                                         \
-  "s_mov_b64 " LT_R_LEAFM ", " HMN "\n"                                                                                         \
-  "s_mov_b32 %[cur], -1\n"                                                                                                      \
-  "s_cmp_lg_u64 " HMF ", 0\n"                                                                                                   \
-  "s_cbranch_scc0 .Lleaf%=\n"                                                                                                   \
-  "s_cmp_lt_i32 " REFF ", 0\n"                                                                                                  \
-  "s_cbranch_scc1 .LfLeaf" TAG "%=\n"                                                                                           \
-  "s_mov_b32 %[cur], " REFF "\n"                    /* then the far child (interior) */                                         \
-  "s_mov_b64 %[mask], " HMF "\n"                                                                                                \
-  "s_branch .Lleaf%=\n"                                                                                                         \
-  ".LfLeaf" TAG "%=:\n"                                                                                                         \
-  LT_ASM_PUSH(REFF, FLO, FHI)                       /* far leaf: next, through the stack */                                     \
-  "s_branch .Lleaf%=\n"                                                                                                         \
-  ".LnMiss" TAG "%=:\n"                             /* only the far child was hit */                                            \
-  "s_cmp_lt_i32 " REFF ", 0\n"                                                                                                  \
-  "s_cbranch_scc1 .LfOnlyLeaf" TAG "%=\n"                                                                                       \
-  "s_mov_b32 %[cur], " REFF "\n"                                                                                                \
-  "s_mov_b64 %[mask], " HMF "\n"                                                                                                \
-  "s_branch .Ltop%=\n"                                                                                                          \
-  ".LfOnlyLeaf" TAG "%=:\n"                                                                                                     \
-  "s_mov_b32 " LT_R_LEAF ", " REFF "\n"                                                                                         \
-  "s_mov_b64 " LT_R_LEAFM ", " HMF "\n"                                                                                         \
-  "s_mov_b32 %[cur], -1\n"                                                                                                      \
-  "s_branch .Lleaf%=\n"
-
-#define LT_ASM_CLOSEST_WALK(BOXES, NEGBITS, ROFF)                                                                                    \
-  "s_mov_b64 " LT_R_EXEC ", exec\n"                                                                                             \
-  ".Ltop%=:\n"                                                                                                                  \
-  LT_ASM_LOAD_NODE                                                                                                              \
-  "s_mov_b64 exec, %[mask]\n"                                                                                                   \
-  BOXES                                                                                                                         \
-  "s_or_b64 " LT_R_TMPM ", " LT_R_HML ", " LT_R_HMR "\n"                                                                         \
-  "s_cbranch_scc0 .Lpop%=\n"                        /* both children missed */                                                  \
-  "s_lshr_b32 " LT_R_PRIM ", %[cur], 29\n"          /* the node's split axis */                                                 \
-  "s_bitcmp1_b32 " NEGBITS ", " LT_R_PRIM "\n"      /* dirIsNeg[axis]: the right child is the near one */                       \
-  "s_cbranch_scc1 .LnearR%=\n"                                                                                                  \
-  LT_ASM_VISIT("a", LT_R_HML, LT_R_REFL, LT_R_HMR, LT_R_REFR, LT_R_HMRLO, LT_R_HMRHI)                                           \
-  ".LnearR%=:\n"                                                                                                                \
-  LT_ASM_VISIT("b", LT_R_HMR, LT_R_REFR, LT_R_HML, LT_R_REFL, LT_R_HMLLO, LT_R_HMLHI)                                           \
-  ".Lpop%=:\n"                                                                                                                  \
-  "s_cmp_eq_u32 %[sp], 0\n"                                                                                                     \
-  "s_cbranch_scc1 .Ldone%=\n"                                                                                                   \
-  LT_ASM_POP_TOP                                                                                                                \
-  "s_cmp_lt_i32 " LT_R_LEAF ", 0\n"                                                                                             \
-  "s_cbranch_scc1 .LpoppedLeaf%=\n"                                                                                             \
-  "s_mov_b32 %[cur], " LT_R_LEAF "\n"                                                                                           \
-  "s_mov_b64 %[mask], " LT_R_TMPM "\n"                                                                                          \
-  "s_branch .Ltop%=\n"                                                                                                          \
-  ".LpoppedLeaf%=:\n"                                                                                                           \
-  "s_mov_b64 " LT_R_LEAFM ", " LT_R_TMPM "\n"                                                                                   \
-  "s_mov_b32 %[cur], -1\n"                                                                                                      \
-  LT_ASM_LEAF_PROLOGUE                                                                                                          \
-  LT_ASM_TRI_PART1                                                                                                              \
-  LT_ASM_TRI_PART2                                                                                                              \
+// what a closest-hit walk does with a triangle's t (EXEC = the lanes that passed every other test)
+#define LT_ASM_ACCEPT_CLOSEST(ROFF)                                                                                             \
   "v_cmp_eq_f32_e64 " LT_R_HMR ", %[t3], %[pt]\n"   /* the same t again, bit for bit? (rare) */                                 \
   "v_cmp_lt_f32_e64 " LT_R_HML ", %[t3], %[pt]\n"   /* t < payload.t (no t > 0 test in the reference) */                        \
   "s_cmp_lg_u64 " LT_R_HMR ", 0\n"                                                                                              \
   "s_cbranch_scc0 .Ltake%=\n"                                                                                                   \
-  /* Two triangles, one t: the reference keeps the one its own depth-first order meets first.  This walk follows the backend's   \
-     tree, so the order comes from the table (SceneDev::rank8: 8 ranks per primitive, one per direction-sign octant). */         \
-  "s_cmp_lg_u64 %[ranks], 0\n"                      /* no table: this IS the reference's order */                               \
-  "s_cbranch_scc0 .Ltake%=\n"                                                                                                   \
+  /* Two triangles, one t: the reference keeps the one its own depth-first order meets first; this walk has no order, so it     \
+     asks the table (SceneDev::rank8: 8 ranks per primitive, one per direction-sign octant). */                                 \
   "s_mov_b64 " LT_R_TMPM ", exec\n"                                                                                             \
   "s_mov_b64 exec, " LT_R_HMR "\n"                                                                                              \
   "v_cmpx_eq_u32_e64 " LT_R_HMR ", 1, %[phit]\n"    /* ... against a hit the lane already holds */                              \
@@ -446,35 +247,146 @@ __device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, const vo
   "v_mov_b32_e32 %[pu], %[t1]\n"                                                                                                \
   "v_mov_b32_e32 %[pv], %[t2]\n"                                                                                                \
   "v_mov_b32_e32 %[pprim], " LT_R_PRIM "\n"                                                                                     \
-  "v_mov_b32_e32 %[phit], 1\n"                                                                                                  \
-  LT_ASM_LEAF_EPILOGUE                                                                                                          \
+  "v_mov_b32_e32 %[phit], 1\n"
+
+// ... and an any-hit walk: the lanes that accept are done; the walk ends when nobody is left
+#define LT_ASM_ACCEPT_ANYHIT                                                                                                    \
+  "v_cmpx_lt_f32_e64 " LT_R_HML ", %[t3], %[tmax]\n" /* t < payload.t: accepted */                                              \
+  "s_andn2_b64 %[open], %[open], exec\n"            /* those lanes are done; SCC = anyone still looking */                      \
+  "s_cbranch_scc0 .Ldone%=\n"
+
+// The walk.  LIVE = the register pair holding the lanes that take part (EXEC on entry for a closest-hit walk, `open` for an
+// any-hit walk); IGNORE = the any-hit walks' "not the primitive the ray starts on" (acc.cl:188); ACCEPT as above.
+#define LT_ASM_WALK(NF, LIVE, IGNORE, ACCEPT)                                                                                   \
+  "s_mov_b64 " LT_R_EXEC ", exec\n"                                                                                             \
+  "s_mov_b32 " LT_R_M0 ", m0\n"                                                                                                 \
+  "s_mov_b32 m0, 0\n"                               /* the stack pointer lives in M0 */                                         \
+  "s_mov_b32 " LT_R_CUR ", 0\n"                     /* the root: interior node 0 */                                             \
+  "s_branch .Lnode%=\n"                                                                                                         \
+  ".Lpop%=:\n"                                                                                                                  \
+  "s_cmp_eq_u32 m0, 0\n"                                                                                                        \
+  "s_cbranch_scc1 .Ldone%=\n"                                                                                                   \
+  "s_sub_u32 m0, m0, 1\n"                                                                                                       \
+  "v_readlane_b32 " LT_R_CUR ", %[stk], m0\n"                                                                                   \
+  "s_cmp_lt_i32 " LT_R_CUR ", 0\n"                                                                                              \
+  "s_cbranch_scc1 .Lleaf%=\n"                                                                                                   \
+  ".Lnode%=:\n"                                                                                                                 \
+  "s_lshl_b32 " LT_R_TMPLO ", " LT_R_CUR ", 6\n"                                                                                \
+  "s_load_dwordx16 " LT_R_REC0 ", %[pairs], " LT_R_TMPLO "\n"                                                                   \
+  "s_cmp_eq_u32 m0, 0\n"                            /* a second interior node to fetch beside it? */                            \
+  "s_cbranch_scc1 .Lone%=\n"                                                                                                    \
+  "s_sub_u32 m0, m0, 1\n"                                                                                                       \
+  "v_readlane_b32 " LT_R_CUR2 ", %[stk], m0\n"                                                                                  \
+  "s_cmp_lt_i32 " LT_R_CUR2 ", 0\n"                                                                                             \
+  "s_cbranch_scc1 .LoneBack%=\n"                    /* a leaf on top: it stays */                                               \
+  "s_lshl_b32 " LT_R_TMPHI ", " LT_R_CUR2 ", 6\n"                                                                               \
+  "s_load_dwordx16 " LT_R_REC1 ", %[pairs], " LT_R_TMPHI "\n"                                                                   \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
+  "s_mov_b64 exec, " LIVE "\n"                                                                                                  \
+  LT_BOXC_N(NF, LT_LOHI_0, LT_R_HML)                                                                                            \
+  LT_BOXC_N(NF, LT_LOHI_1, LT_R_HMR)                                                                                            \
+  LT_ASM_PUSH(LT_R_REF0L, LT_R_HML)                                                                                             \
+  LT_ASM_PUSH(LT_R_REF0R, LT_R_HMR)                                                                                             \
+  LT_BOXC_N(NF, LT_LOHI_2, LT_R_HML)                                                                                            \
+  LT_BOXC_N(NF, LT_LOHI_3, LT_R_HMR)                                                                                            \
+  LT_ASM_PUSH(LT_R_REF1L, LT_R_HML)                                                                                             \
+  LT_ASM_PUSH(LT_R_REF1R, LT_R_HMR)                                                                                             \
+  "s_branch .Lpop%=\n"                                                                                                          \
+  ".LoneBack%=:\n"                                                                                                              \
+  "s_add_u32 m0, m0, 1\n"                                                                                                       \
+  ".Lone%=:\n"                                                                                                                  \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
+  "s_mov_b64 exec, " LIVE "\n"                                                                                                  \
+  LT_BOXC_N(NF, LT_LOHI_0, LT_R_HML)                                                                                            \
+  LT_BOXC_N(NF, LT_LOHI_1, LT_R_HMR)                                                                                            \
+  LT_ASM_PUSH(LT_R_REF0L, LT_R_HML)                                                                                             \
+  LT_ASM_PUSH(LT_R_REF0R, LT_R_HMR)                                                                                             \
+  "s_branch .Lpop%=\n"                                                                                                          \
+  ".Lleaf%=:\n"                                                                                                                 \
+  "s_lshl_b32 " LT_R_TMPLO ", " LT_R_CUR ", 6\n"    /* (bit 31 falls off the 32-bit byte offset) */                             \
+  "s_load_dwordx16 " LT_R_REC0 ", %[pairs], " LT_R_TMPLO "\n"                                                                   \
+  "s_mov_b64 exec, " LIVE "\n"                                                                                                  \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
+  LT_BOXX_N(NF, LT_LOHI_LEAF)                       /* the reference's own test of the leaf's own box */                        \
+  IGNORE                                                                                                                        \
+  "s_cbranch_execz .LleafEnd%=\n"                                                                                               \
+  LT_ASM_TRI_PART1                                                                                                              \
+  LT_ASM_TRI_PART2                                                                                                              \
+  ACCEPT                                                                                                                        \
+  ".LleafEnd%=:\n"                                                                                                              \
+  "s_branch .Lpop%=\n"                                                                                                          \
   ".Ldone%=:\n"                                                                                                                 \
+  "s_mov_b32 m0, " LT_R_M0 "\n"                                                                                                 \
   "s_mov_b64 exec, " LT_R_EXEC "\n"
 
-// The whole closest-hit walk below the root.  `cur` = the root's reference (index 0 | its split axis << 29), `mask` = the lanes
-// that hit the root's box.
+#define LT_ASM_IGNORE_ANYHIT "v_cmpx_ne_u32_e64 " LT_R_HML ", " LT_R_PRIM ", %[ign]\n"
+
+// Per-ray constants of the conservative test.
+struct PacketRay {
+  float px, py, pz, mg;
+};
+__device__ __forceinline__ PacketRay packet_ray(float ox, float oy, float oz, float ix, float iy, float iz) {
+  PacketRay r;
+  r.px = ox * ix;
+  r.py = oy * iy;
+  r.pz = oz * iz;
+  r.mg = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(r.px), __builtin_fabsf(r.py)), __builtin_fabsf(r.pz)) * 0x1p-19f + 0x1p-140f;
+  return r;
+}
+
+// The any-hit walk: on return `open` holds the lanes that found no occluder.  NEG = the direction-sign octant all rays of the wave
+// share; eps = the program's triangle epsilon as the float the reference's double compare amounts to (intersect_triangle_data).
 template <int NEG>
-__device__ __forceinline__ void packet_closest_walk(const void* pairs, const void* tris, const void* ranks, float ox, float oy, float oz, float ix, float iy,
-                                                    float iz, float dx, float dy, float dz, float dw, float eps, uint32_t fast, uint32_t lds,
-                                                    uint32_t cur, lt_u64 mask, float& pt, float& pu, float& pv, int& pprim, int& phit) {
-  uint32_t sp = 0u;
+__device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, float ox, float oy, float oz, float ix, float iy, float iz, float dx,
+                                                     float dy, float dz, float dw, float tmax, int ign, float eps, uint32_t fast, lt_u64 open) {
+  const PacketRay pr = packet_ray(ox, oy, oz, ix, iy, iz);
+  int stk = 0;
   float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
-#define LT_CLOSEST_INSTANCE(BOXES, NEGBITS, ROFF)                                                                                            \
-  asm volatile(LT_ASM_CLOSEST_WALK(BOXES, NEGBITS, ROFF)                                                                                     \
-               : [cur] "+s"(cur), [mask] "+s"(mask), [sp] "+s"(sp), [pt] "+v"(pt), [pu] "+v"(pu), [pv] "+v"(pv), [pprim] "+v"(pprim),    \
-                 [phit] "+v"(phit), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),     \
-                 [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9), [t10] "=&v"(t10)                                        \
-               : [pairs] "s"(pairs), [tris] "s"(tris), [ranks] "s"(ranks), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), \
-                 [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [dw] "v"(dw), [eps] "s"(eps), [fast] "s"(fast), [lds] "v"(lds)                  \
+#define LT_ANYHIT_INSTANCE(NF)                                                                                                           \
+  asm volatile(LT_ASM_WALK(NF, "%[open]", LT_ASM_IGNORE_ANYHIT, LT_ASM_ACCEPT_ANYHIT)                                                    \
+               : [open] "+s"(open), [stk] "+v"(stk), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4),     \
+                 [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9), [t10] "=&v"(t10)                        \
+               : [pairs] "s"(pairs), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [px] "v"(pr.px),  \
+                 [py] "v"(pr.py), [pz] "v"(pr.pz), [mg] "v"(pr.mg), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [dw] "v"(dw),                \
+                 [tmax] "v"(tmax), [ign] "v"(ign), [eps] "s"(eps), [fast] "s"(fast)                                                       \
                : LT_ASM_CLOBBERS)
-  if constexpr (NEG == 0) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_0, "0", "0");
-  else if constexpr (NEG == 1) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_1, "1", "4");
-  else if constexpr (NEG == 2) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_2, "2", "8");
-  else if constexpr (NEG == 3) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_3, "3", "12");
-  else if constexpr (NEG == 4) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_4, "4", "16");
-  else if constexpr (NEG == 5) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_5, "5", "20");
-  else if constexpr (NEG == 6) LT_CLOSEST_INSTANCE(LT_ASM_BOXES_6, "6", "24");
-  else LT_CLOSEST_INSTANCE(LT_ASM_BOXES_7, "7", "28");
+  if constexpr (NEG == 0) LT_ANYHIT_INSTANCE(LT_NF_0);
+  else if constexpr (NEG == 1) LT_ANYHIT_INSTANCE(LT_NF_1);
+  else if constexpr (NEG == 2) LT_ANYHIT_INSTANCE(LT_NF_2);
+  else if constexpr (NEG == 3) LT_ANYHIT_INSTANCE(LT_NF_3);
+  else if constexpr (NEG == 4) LT_ANYHIT_INSTANCE(LT_NF_4);
+  else if constexpr (NEG == 5) LT_ANYHIT_INSTANCE(LT_NF_5);
+  else if constexpr (NEG == 6) LT_ANYHIT_INSTANCE(LT_NF_6);
+  else LT_ANYHIT_INSTANCE(LT_NF_7);
+#undef LT_ANYHIT_INSTANCE
+  return open;
+}
+
+// The closest-hit walk (camera rays).
+template <int NEG>
+__device__ __forceinline__ void packet_closest_walk(const void* pairs, const void* ranks, float ox, float oy, float oz, float ix, float iy,
+                                                    float iz, float dx, float dy, float dz, float dw, float eps, uint32_t fast, float& pt,
+                                                    float& pu, float& pv, int& pprim, int& phit) {
+  const PacketRay pr = packet_ray(ox, oy, oz, ix, iy, iz);
+  int stk = 0;
+  float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
+#define LT_CLOSEST_INSTANCE(NF, ROFF)                                                                                                    \
+  asm volatile(LT_ASM_WALK(NF, LT_R_EXEC, "", LT_ASM_ACCEPT_CLOSEST(ROFF))                                                               \
+               : [pt] "+v"(pt), [pu] "+v"(pu), [pv] "+v"(pv), [pprim] "+v"(pprim), [phit] "+v"(phit), [stk] "+v"(stk), [t0] "=&v"(t0),   \
+                 [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7),         \
+                 [t8] "=&v"(t8), [t9] "=&v"(t9), [t10] "=&v"(t10)                                                                        \
+               : [pairs] "s"(pairs), [ranks] "s"(ranks), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy),            \
+                 [iz] "v"(iz), [px] "v"(pr.px), [py] "v"(pr.py), [pz] "v"(pr.pz), [mg] "v"(pr.mg), [dx] "v"(dx), [dy] "v"(dy),            \
+                 [dz] "v"(dz), [dw] "v"(dw), [eps] "s"(eps), [fast] "s"(fast)                                                             \
+               : LT_ASM_CLOBBERS)
+  if constexpr (NEG == 0) LT_CLOSEST_INSTANCE(LT_NF_0, "0");
+  else if constexpr (NEG == 1) LT_CLOSEST_INSTANCE(LT_NF_1, "4");
+  else if constexpr (NEG == 2) LT_CLOSEST_INSTANCE(LT_NF_2, "8");
+  else if constexpr (NEG == 3) LT_CLOSEST_INSTANCE(LT_NF_3, "12");
+  else if constexpr (NEG == 4) LT_CLOSEST_INSTANCE(LT_NF_4, "16");
+  else if constexpr (NEG == 5) LT_CLOSEST_INSTANCE(LT_NF_5, "20");
+  else if constexpr (NEG == 6) LT_CLOSEST_INSTANCE(LT_NF_6, "24");
+  else LT_CLOSEST_INSTANCE(LT_NF_7, "28");
 #undef LT_CLOSEST_INSTANCE
 }
 

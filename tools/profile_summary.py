@@ -39,8 +39,8 @@ def dominant(per_kernel, counter):
     """the non-counting render kernel (or GI stage set) with the largest total of `counter`"""
     best = None
     for k, cs in per_kernel.items():
-        m = re.search(r"Config<(\w+), (\w+), (\w+)>", k)
-        if "lt_" not in k or (m and m.group(2) == "true"):   # (Config<DEEP, STATS, DEVLIBM>: skip the counting instantiations)
+        m = re.search(r"Config<(\w+), (\w+), (\w+)(?:, (\w+))?>", k)
+        if "lt_" not in k or (m and m.group(2) == "true"):   # (Config<DEEP, STATS, DEVLIBM, LDSSCENE>: skip the counting instantiations)
             continue
         if counter in cs and (best is None or cs[counter] * dispatches.get(k, 1) > per_kernel[best][counter] * dispatches.get(best, 1)):
             best = k      # (the largest TOTAL over the run: mean per dispatch x dispatches)
