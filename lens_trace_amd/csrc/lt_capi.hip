@@ -931,6 +931,10 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   fp.yaw = cam[3];
   fp.width = d->width; fp.height = d->height; fp.depth = d->depth;
   fp.clampOutput = d->kernel_mode == LT_KERNEL_MODE_LINEAR;
+  {
+    const char* sm = getenv("LT_SQUARE_MAJOR");
+    fp.squareMajor = (sm && atoi(sm) == 0) ? 0u : 1u;
+  }
   fp.giMaxDepth = d->gi_max_depth ? d->gi_max_depth : 16;
   fp.tileW = p.tileW; fp.tileH = p.tileH; fp.tilesX = p.tilesX; fp.tileFirst = p.tileFirst; fp.tileStride = p.tileStride;
   fp.tilesInCall = p.tilesInCall;

@@ -1144,6 +1144,7 @@ struct FrameParams {
   // several samples in one launch (persistent mode): work item = (frame f, square), frame f uses frameCount + f and stores
   // its colours, un-accumulated, at out + f * frameStride; lt_running_mean_kernel folds them in frame order afterwards
   uint32_t fusedFrames;                     // >= 1
+  uint32_t squareMajor;                     // != 0: a queue hands out the frames of a square one after the other (else a frame's squares)
   unsigned long long frameStride;           // floats between the sample images of a fused launch
   // persistent mode: the order in which an XCD's share of squares is handed out (position -> square index), or null for
   // the natural order.  The host puts the squares that cannot take the fast path (a pixel with an exactly-zero direction

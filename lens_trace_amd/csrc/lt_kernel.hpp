@@ -111,8 +111,13 @@ __device__ __forceinline__ void render_kernel_body(const SceneDev& sc, const Fra
         t -= frame * head;
       } else if (fp.fusedFrames > 1u) {
         t -= head * fp.fusedFrames;
-        frame = t / (share - head);
-        t = head + (t - frame * (share - head));
+        if (fp.squareMajor) {   // the frames of a square side by side: their rays meet the same nodes while those are in the L2
+          frame = t % fp.fusedFrames;
+          t = head + t / fp.fusedFrames;
+        } else {
+          frame = t / (share - head);
+          t = head + (t - frame * (share - head));
+        }
       }
       b = start + t;
       if (fp.order) b = (uint32_t)__builtin_amdgcn_readfirstlane((int)fp.order[b]);
