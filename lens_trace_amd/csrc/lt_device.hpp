@@ -749,7 +749,7 @@ __device__ inline void packet_walk_cpp(const SceneDev& sc, const Ray& ray, float
 template <int PROGRAM, int NEG, bool ANYHIT>
 __device__ __forceinline__ void packet_walk(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl, int* ldsWave) {
 #ifndef LT_NO_ASM_WALKS
-  if constexpr (NEG >= 0) {
+  if constexpr (NEG >= 0 || ANYHIT) {
     const float eps = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
                       : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
     if constexpr (ANYHIT) {
@@ -850,8 +850,8 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
           default: packet_walk<PROGRAM, 7, true>(sc, ray, ix, iy, iz, ign, pl, row); return;
         }
       }
-      // (a wave whose rays do not share an octant walks per lane: the sign-generic C++ form of the packet walk costs the
-      // 1 M-triangle frame 6 %, 21.3 against 20.0 ms)
+      packet_walk<PROGRAM, -1, true>(sc, ray, ix, iy, iz, ign, pl, row);   // (the sign-generic form of the walk)
+      return;
     }
     if constexpr (!STATS && !LDSSCENE) {
       if (sc.rank8 != nullptr) {   // (the scene has a tree of the backend's own: lt_hip_set_scene)

@@ -130,20 +130,72 @@ typedef unsigned long long lt_u64;
 #define LT_LOHI_2 "s52", "s53", "s54", "s55", "s56", "s57"
 #define LT_LOHI_3 "s60", "s61", "s62", "s63", "s64", "s65"
 #define LT_LOHI_LEAF "s45", "s46", "s47", "s48", "s49", "s50"
-// (lo.x lo.y lo.z hi.x hi.y hi.z) -> (near.x near.y near.z far.x far.y far.z) for the octant NEG: the near plane of axis a is the
-// box's max when direction component a is negative (bit a of NEG)
-#define LT_NF_0(LX, LY, LZ, HX, HY, HZ) LX, LY, LZ, HX, HY, HZ
-#define LT_NF_1(LX, LY, LZ, HX, HY, HZ) HX, LY, LZ, LX, HY, HZ
-#define LT_NF_2(LX, LY, LZ, HX, HY, HZ) LX, HY, LZ, HX, LY, HZ
-#define LT_NF_3(LX, LY, LZ, HX, HY, HZ) HX, HY, LZ, LX, LY, HZ
-#define LT_NF_4(LX, LY, LZ, HX, HY, HZ) LX, LY, HZ, HX, HY, LZ
-#define LT_NF_5(LX, LY, LZ, HX, HY, HZ) HX, LY, HZ, LX, HY, LZ
-#define LT_NF_6(LX, LY, LZ, HX, HY, HZ) LX, HY, HZ, HX, LY, LZ
-#define LT_NF_7(LX, LY, LZ, HX, HY, HZ) HX, HY, HZ, LX, LY, LZ
-#define LT_APPLY(M, ...) M(__VA_ARGS__)
-#define LT_ASM_BOXC_OUT(OUT, NX, NY, NZ, FX, FY, FZ) LT_ASM_BOXC(NX, NY, NZ, FX, FY, FZ, OUT)
-#define LT_BOXC_N(NF, LOHI, OUT) LT_APPLY(LT_ASM_BOXC_OUT, OUT, LT_APPLY(NF, LOHI))
-#define LT_BOXX_N(NF, LOHI) LT_APPLY(LT_ASM_BOXX, LT_APPLY(NF, LOHI))
+// ... and for a wave whose rays do not share an octant (shadow rays around a light overhead): the same two tests with each
+// axis' near / far plane picked per lane, min / max of the two products (fma and (bound - o) * inv are monotonic in the bound and
+// lo <= hi, so the smaller product is the near plane's): 17 and 22 instructions
+#define LT_ASM_BOXC_G(LX, LY, LZ, HX, HY, HZ, OUT)     \
+  "v_fma_f32 %[t0], " LX ", %[ix], -%[px]\n"          \
+  "v_fma_f32 %[t1], " HX ", %[ix], -%[px]\n"          \
+  "v_fma_f32 %[t2], " LY ", %[iy], -%[py]\n"          \
+  "v_fma_f32 %[t3], " HY ", %[iy], -%[py]\n"          \
+  "v_fma_f32 %[t4], " LZ ", %[iz], -%[pz]\n"          \
+  "v_fma_f32 %[t5], " HZ ", %[iz], -%[pz]\n"          \
+  "v_min_f32_e32 %[t6], %[t0], %[t1]\n"               \
+  "v_min_f32_e32 %[t7], %[t2], %[t3]\n"               \
+  "v_min_f32_e32 %[t8], %[t4], %[t5]\n"               \
+  "v_max_f32_e32 %[t0], %[t0], %[t1]\n"               \
+  "v_max_f32_e32 %[t2], %[t2], %[t3]\n"               \
+  "v_max_f32_e32 %[t4], %[t4], %[t5]\n"               \
+  "v_max3_f32 %[t6], %[t6], %[t7], %[t8]\n"           \
+  "v_min3_f32 %[t0], %[t0], %[t2], %[t4]\n"           \
+  "v_add_f32_e32 %[t0], %[t0], %[mg]\n"               \
+  "v_max_f32_e32 %[t6], 1, %[t6]\n"                   \
+  "v_cmp_ge_f32_e64 " OUT ", %[t0], %[t6]\n"
+#define LT_ASM_BOXX_G(LX, LY, LZ, HX, HY, HZ)          \
+  "v_sub_f32_e32 %[t0], " LX ", %[ox]\n"              \
+  "v_sub_f32_e32 %[t1], " HX ", %[ox]\n"              \
+  "v_sub_f32_e32 %[t2], " LY ", %[oy]\n"              \
+  "v_sub_f32_e32 %[t3], " HY ", %[oy]\n"              \
+  "v_sub_f32_e32 %[t4], " LZ ", %[oz]\n"              \
+  "v_sub_f32_e32 %[t5], " HZ ", %[oz]\n"              \
+  "v_mul_f32_e32 %[t0], %[t0], %[ix]\n"               \
+  "v_mul_f32_e32 %[t1], %[t1], %[ix]\n"               \
+  "v_mul_f32_e32 %[t2], %[t2], %[iy]\n"               \
+  "v_mul_f32_e32 %[t3], %[t3], %[iy]\n"               \
+  "v_mul_f32_e32 %[t4], %[t4], %[iz]\n"               \
+  "v_mul_f32_e32 %[t5], %[t5], %[iz]\n"               \
+  "v_min_f32_e32 %[t6], %[t0], %[t1]\n"               \
+  "v_min_f32_e32 %[t7], %[t2], %[t3]\n"               \
+  "v_min_f32_e32 %[t8], %[t4], %[t5]\n"               \
+  "v_max_f32_e32 %[t0], %[t0], %[t1]\n"               \
+  "v_max_f32_e32 %[t2], %[t2], %[t3]\n"               \
+  "v_max_f32_e32 %[t4], %[t4], %[t5]\n"               \
+  "v_max3_f32 %[t6], %[t6], %[t7], %[t8]\n"           \
+  "v_min3_f32 %[t0], %[t0], %[t2], %[t4]\n"           \
+  "v_max_f32_e32 %[t6], 1, %[t6]\n"                   \
+  "v_cmpx_ge_f32_e64 " LT_R_HML ", %[t0], %[t6]\n"
+// What LT_ASM_WALK takes as its first argument, LT_NF_<octant> or LT_NF_G, names a pair of tests: for the octant NEG the near
+// plane of axis a is the box's max when direction component a is negative (bit a of NEG).
+#define LT_BC_LT_NF_0(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(LX, LY, LZ, HX, HY, HZ, OUT)
+#define LT_BX_LT_NF_0(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(LX, LY, LZ, HX, HY, HZ)
+#define LT_BC_LT_NF_1(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(HX, LY, LZ, LX, HY, HZ, OUT)
+#define LT_BX_LT_NF_1(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(HX, LY, LZ, LX, HY, HZ)
+#define LT_BC_LT_NF_2(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(LX, HY, LZ, HX, LY, HZ, OUT)
+#define LT_BX_LT_NF_2(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(LX, HY, LZ, HX, LY, HZ)
+#define LT_BC_LT_NF_3(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(HX, HY, LZ, LX, LY, HZ, OUT)
+#define LT_BX_LT_NF_3(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(HX, HY, LZ, LX, LY, HZ)
+#define LT_BC_LT_NF_4(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(LX, LY, HZ, HX, HY, LZ, OUT)
+#define LT_BX_LT_NF_4(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(LX, LY, HZ, HX, HY, LZ)
+#define LT_BC_LT_NF_5(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(HX, LY, HZ, LX, HY, LZ, OUT)
+#define LT_BX_LT_NF_5(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(HX, LY, HZ, LX, HY, LZ)
+#define LT_BC_LT_NF_6(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(LX, HY, HZ, HX, LY, LZ, OUT)
+#define LT_BX_LT_NF_6(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(LX, HY, HZ, HX, LY, LZ)
+#define LT_BC_LT_NF_7(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(HX, HY, HZ, LX, LY, LZ, OUT)
+#define LT_BX_LT_NF_7(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(HX, HY, HZ, LX, LY, LZ)
+#define LT_BC_LT_NF_G(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC_G(LX, LY, LZ, HX, HY, HZ, OUT)
+#define LT_BX_LT_NF_G(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX_G(LX, LY, LZ, HX, HY, HZ)
+#define LT_BC(NF, LOHI, OUT) LT_BC_##NF(LOHI, OUT)
+#define LT_BX(NF, LOHI) LT_BX_##NF(LOHI)
 
 // branch-free push of a child reference: written at the top, kept iff some lane hit the child
 #define LT_ASM_PUSH(REF, HM)                        \
@@ -283,12 +335,12 @@ typedef unsigned long long lt_u64;
   "s_load_dwordx16 " LT_R_REC1 ", %[pairs], " LT_R_TMPHI "\n"                                                                   \
   "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
   "s_mov_b64 exec, " LIVE "\n"                                                                                                  \
-  LT_BOXC_N(NF, LT_LOHI_0, LT_R_HML)                                                                                            \
-  LT_BOXC_N(NF, LT_LOHI_1, LT_R_HMR)                                                                                            \
+  LT_BC(NF, LT_LOHI_0, LT_R_HML)                                                                                               \
+  LT_BC(NF, LT_LOHI_1, LT_R_HMR)                                                                                               \
   LT_ASM_PUSH(LT_R_REF0L, LT_R_HML)                                                                                             \
   LT_ASM_PUSH(LT_R_REF0R, LT_R_HMR)                                                                                             \
-  LT_BOXC_N(NF, LT_LOHI_2, LT_R_HML)                                                                                            \
-  LT_BOXC_N(NF, LT_LOHI_3, LT_R_HMR)                                                                                            \
+  LT_BC(NF, LT_LOHI_2, LT_R_HML)                                                                                               \
+  LT_BC(NF, LT_LOHI_3, LT_R_HMR)                                                                                               \
   LT_ASM_PUSH(LT_R_REF1L, LT_R_HML)                                                                                             \
   LT_ASM_PUSH(LT_R_REF1R, LT_R_HMR)                                                                                             \
   "s_branch .Lpop%=\n"                                                                                                          \
@@ -297,8 +349,8 @@ typedef unsigned long long lt_u64;
   ".Lone%=:\n"                                                                                                                  \
   "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
   "s_mov_b64 exec, " LIVE "\n"                                                                                                  \
-  LT_BOXC_N(NF, LT_LOHI_0, LT_R_HML)                                                                                            \
-  LT_BOXC_N(NF, LT_LOHI_1, LT_R_HMR)                                                                                            \
+  LT_BC(NF, LT_LOHI_0, LT_R_HML)                                                                                               \
+  LT_BC(NF, LT_LOHI_1, LT_R_HMR)                                                                                               \
   LT_ASM_PUSH(LT_R_REF0L, LT_R_HML)                                                                                             \
   LT_ASM_PUSH(LT_R_REF0R, LT_R_HMR)                                                                                             \
   "s_branch .Lpop%=\n"                                                                                                          \
@@ -307,7 +359,7 @@ typedef unsigned long long lt_u64;
   "s_load_dwordx16 " LT_R_REC0 ", %[pairs], " LT_R_TMPLO "\n"                                                                   \
   "s_mov_b64 exec, " LIVE "\n"                                                                                                  \
   "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
-  LT_BOXX_N(NF, LT_LOHI_LEAF)                       /* the reference's own test of the leaf's own box */                        \
+  LT_BX(NF, LT_LOHI_LEAF)                           /* the reference's own test of the leaf's own box */                        \
   IGNORE                                                                                                                        \
   "s_cbranch_execz .LleafEnd%=\n"                                                                                               \
   LT_ASM_TRI_PART1                                                                                                              \
@@ -357,7 +409,8 @@ __device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, float ox
   else if constexpr (NEG == 4) LT_ANYHIT_INSTANCE(LT_NF_4);
   else if constexpr (NEG == 5) LT_ANYHIT_INSTANCE(LT_NF_5);
   else if constexpr (NEG == 6) LT_ANYHIT_INSTANCE(LT_NF_6);
-  else LT_ANYHIT_INSTANCE(LT_NF_7);
+  else if constexpr (NEG == 7) LT_ANYHIT_INSTANCE(LT_NF_7);
+  else LT_ANYHIT_INSTANCE(LT_NF_G);   // NEG < 0: the rays' direction signs differ
 #undef LT_ANYHIT_INSTANCE
   return open;
 }
