@@ -179,8 +179,14 @@ int lt_hip_resolve_program(lt_hip_context* ctx, const char* kernel_file_path, in
 /* Uploads (host pointers) and validates the four scene buffers; keeps them resident until the next
  * set_scene / destroy.  A call whose four buffers have the sizes and the content (a hash of every byte) of the resident
  * scene returns at once and keeps it: callers may pass their scene on every render, as the reference does
- * (renderer_opencl.cpp:107-120), and in-place edits are honoured.  Also builds the traversal-side triangle array (48-byte stride: A, B-A, C-A).  The BVH is
- * traversed in the uploaded LinearBVHNode layout itself. */
+ * (renderer_opencl.cpp:107-120), and in-place edits are honoured.
+ * Derived at upload: the traversal-side triangle array (48-byte stride: A, B-A, C-A) and -- when every node's box encloses
+ * its children's, which the reference's own builder guarantees -- the backend's OWN hierarchy over the caller's leaves
+ * (binned surface-area heuristic, built on the host: ~1.5 s for a million triangles), the 64-byte records of its packet
+ * walks and the reference's leaf order per direction-sign octant.  The caller's LinearBVHNode array stays resident and is
+ * what the counting kernels (LT_RENDER_FLAG_STATS / _PIXEL_COUNTERS), rays with a non-finite component and scenes whose
+ * boxes do not nest walk, in the reference's order.  Pixels do not depend on which hierarchy a ray walked
+ * (lens_trace_amd/csrc/lt_retree.hpp).  LT_RETREE=0 keeps the caller's splits. */
 int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims,
                      uint64_t prim_bytes, const void* materials, uint64_t material_bytes, const void* lights,
                      uint64_t light_bytes);
@@ -203,6 +209,15 @@ int lt_hip_untile(lt_hip_context* ctx, const float* gathered, uint64_t floats_pe
                   float* image_out, void* hip_stream);
 
 int lt_hip_synchronize(lt_hip_context* ctx, void* hip_stream);
+
+/* Host only, no context, no GPU: the hierarchy lt_hip_set_scene would build over the leaves of `nodes` (LinearBVHNode array,
+ * node_bytes = 32 * count), written to out_nodes (capacity out_bytes; 32 bytes x (2 x leaves - 1)) in the caller's own layout
+ * and pre-order numbering, and, when rank8 != NULL, the reference's leaf order (8 uint32 per primitive, n_prims primitives:
+ * position of the primitive's leaf in the reference's depth-first order for each direction-sign octant).  Returns the
+ * hierarchy's height, or -1 when the scene gets none (boxes that do not nest, fewer than two leaves, bounds >= 2^40).
+ * height_slack: levels allowed above ceil(log2 leaves) (lt_hip_set_scene uses 2); < 0 copies the caller's splits. */
+int lt_hip_own_hierarchy(const void* nodes, uint64_t node_bytes, int height_slack, void* out_nodes, uint64_t out_bytes,
+                         uint32_t* rank8, uint32_t n_prims);
 
 /* Statistics of the most recent render call on ctx (waits for it to finish). */
 int lt_hip_get_stats(lt_hip_context* ctx, lt_hip_stats* out);

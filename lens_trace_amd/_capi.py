@@ -24,7 +24,7 @@ RENDER_FLAG_STRICT_MATH = 16
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",
            "lt_hip_resolve_program",
            "lt_hip_set_scene", "lt_hip_output_floats", "lt_hip_render", "lt_hip_render_device", "lt_hip_untile",
-           "lt_hip_synchronize", "lt_hip_get_stats"]
+           "lt_hip_synchronize", "lt_hip_get_stats", "lt_hip_own_hierarchy"]
 
 
 class RenderDesc(ctypes.Structure):
@@ -107,3 +107,20 @@ def program_from_path(path):
     if rc:
         raise LensTraceError(rc, "no built-in program for kernel file %r" % path)
     return out.value
+
+
+def own_hierarchy(nodes, n_prims=0, height_slack=2, want_ranks=False):
+    """lt_hip_own_hierarchy (host only): (height, nodes of the backend's own hierarchy as a NODE_DTYPE array, rank8 or None);
+    height -1 and no arrays when the scene gets none."""
+    import numpy as np
+    from . import scene as sc
+    nodes = np.ascontiguousarray(nodes)
+    leaves = int((nodes["primitiveCount"] != 0).sum())
+    out = np.zeros(max(1, 2 * leaves - 1), dtype=sc.NODE_DTYPE)
+    ranks = np.zeros((max(1, n_prims), 8), dtype=np.uint32) if want_ranks else None
+    h = load().lt_hip_own_hierarchy(nodes.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(nodes.nbytes), ctypes.c_int(height_slack),
+                                    out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(out.nbytes),
+                                    ranks.ctypes.data_as(ctypes.c_void_p) if want_ranks else None, ctypes.c_uint32(n_prims))
+    if h < 0:
+        return -1, None, None
+    return h, out, ranks

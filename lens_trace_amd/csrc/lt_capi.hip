@@ -431,6 +431,32 @@ static uint64_t hash_bytes(const void* data, uint64_t n, uint64_t seed) {
   return r;
 }
 
+extern "C" int lt_hip_own_hierarchy(const void* nodes, uint64_t node_bytes, int height_slack, void* out_nodes, uint64_t out_bytes,
+                                    uint32_t* rank8, uint32_t n_prims) {
+  if (!nodes || node_bytes == 0 || node_bytes % 32 || node_bytes > 0xffffffffull) return -1;
+  const uint32_t n_nodes = (uint32_t)(node_bytes / 32);
+  {   // the same structural checks lt_hip_set_scene makes before it looks at a buffer (indices in range, forward-only children)
+    const lt_retree::Node* nd = (const lt_retree::Node*)nodes;
+    for (uint32_t i = 0; i < n_nodes; i++) {
+      if (nd[i].cnt != 0) { if (nd[i].off < 0 || (rank8 && (uint32_t)nd[i].off >= n_prims)) return -1; }
+      else if (i + 1 >= n_nodes || nd[i].off <= (int32_t)i + 1 || (uint32_t)nd[i].off >= n_nodes || nd[i].axis > 2) return -1;
+    }
+  }
+  std::vector<lt_retree::Node> own;
+  const int h = height_slack < 0 ? lt_retree::copy(nodes, n_nodes, 30, own) : lt_retree::build(nodes, n_nodes, 30, height_slack, own);
+  if (h < 0) return -1;
+  if (out_nodes) {
+    if (out_bytes < own.size() * sizeof(lt_retree::Node)) return -1;
+    memcpy(out_nodes, own.data(), own.size() * sizeof(lt_retree::Node));
+  }
+  if (rank8) {
+    std::vector<uint32_t> r;
+    lt_retree::reference_order(nodes, n_prims, r);
+    memcpy(rank8, r.data(), r.size() * sizeof(uint32_t));
+  }
+  return h;
+}
+
 extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims,
                                 uint64_t prim_bytes, const void* materials, uint64_t material_bytes, const void* lights,
                                 uint64_t light_bytes) {
