@@ -235,6 +235,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    own_tree = (r.stats()["own_tree_height"], r.stats()["own_tree_ms"])
     t0 = time.perf_counter()
     shadow_walk = -1
     kernel_ms = 0.0
@@ -282,8 +283,12 @@ def main():
             "note": "math flavour = the library default, bit-identical to the reference's OpenCL kernels built for gfx950 as the "
                     "reference builds them (NULL build options, renderer_opencl.cpp:50) -- whole 4K frame of this workload in "
                     "tests/test_gpu_full_size.py; "
-                    "shadow rays stop at the first accepted hit (their callers read only hitType): same pixels, fewer node visits "
-                    "than the reference algorithm, whose counts (measured once with the counting kernel) price roofline.algorithmic_gbs",
+                    "finite rays walk the backend's own binned-SAH hierarchy over the caller's leaves (built at set_scene; a ray "
+                    "reaches the same leaves through any nested hierarchy: lens_trace_amd/csrc/lt_retree.hpp) and shadow rays stop at "
+                    "the first accepted hit (their callers read only hitType): same pixels, fewer node visits than the reference "
+                    "algorithm, whose ray / node / triangle counts (measured once with the counting kernel, which walks the caller's "
+                    "tree in the reference's order) define the rays of `value` and price roofline.algorithmic_gbs; "
+                    "config.callers_splits_* = the same walks over the caller's own splits (LT_RETREE=0)",
             "config": {"workload": "%s, %d triangles, %dx%d, %d spp running mean, program %s, %s" % (
                            scene_name, scene.n_prims, W, H, args.spp, args.program,
                            "whole image on 1 GPU" if world == 1 else "%dx%d tiles interleaved over %d GPUs + 1 RCCL gather" % (plan.tile_w, plan.tile_h, world)),
@@ -292,14 +297,18 @@ def main():
                        "rays_per_frame": rays_total, "node_visits_per_ray": nodes_total / rays_total,
                        "tri_tests_per_ray": tris_total / rays_total, "kernel_only_mrays_per_s": round(rays_total * args.steps / kernel_s / 1e6, 2),
                        "frame_ms": round(ms_per_step, 3),
-                       # which of its two (pixel-identical) walks the library timed faster for this scene's shadow rays
-                       "shadow_ray_walk": SHADOW_WALKS.get(shadow_walk, "not timed")},
+                       # which of its three (pixel-identical) walks the library timed fastest for this scene's shadow rays
+                       "shadow_ray_walk": SHADOW_WALKS.get(shadow_walk, "not timed"),
+                       # the backend's own hierarchy over the caller's leaves: height, host build time at set_scene (not in any step)
+                       "own_hierarchy_height": own_tree[0], "own_hierarchy_build_ms": round(own_tree[1], 1)},
             "roofline": roofline("%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program),
                                  "lt_render_kernel<%s>" % args.program if launches_per_step <= args.spp else "wavefront GI pipeline (all its stage kernels)",
                                  launch_ms, launches_per_step, args.spp, my_alg_bytes_per_launch, world == 1),
         }
         if world == 1 and args.scene == "wall" and not args.no_soup:
-            # the headline scene is the coherent one; the same kernel on config 4's seeded triangle-soup variant beside it
+            # the same walks over the caller's own (median-split) hierarchy ...
+            out["config"].update(callers_splits_figure(args, scene, program, dev, stream, rays_total))
+            # ... and: the headline scene is the coherent one; the same kernel on config 4's seeded triangle-soup variant beside it
             out["config"].update(soup_figure(args, r, program, dev, stream))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, scene, program)
@@ -308,6 +317,39 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     r.close()
+
+
+def callers_splits_figure(args, scene, program, dev, stream, rays_per_step):
+    """The same workload with LT_RETREE=0: the walks' structures are built over the caller's own splits (the reference builder's
+    median splits for the default --bvh) instead of the backend's binned-SAH splits.  Same pixels; a few whole steps."""
+    import torch
+    from lens_trace_amd.renderer import RendererHIP, make_desc
+    old = os.environ.get("LT_RETREE")
+    os.environ["LT_RETREE"] = "0"
+    try:
+        r2 = RendererHIP(0)
+        r2.set_scene(scene)
+    finally:
+        if old is None:
+            del os.environ["LT_RETREE"]
+        else:
+            os.environ["LT_RETREE"] = old
+    W, H, D = args.width, args.height, 3
+    d = make_desc(program, W, H, D, scene.camera, frame_first=1, frame_count=args.spp, accumulate=True, accumulate_base=0)
+    buf = torch.zeros(r2.output_floats(d), dtype=torch.float32, device=dev)
+    for _ in range(2):     # allocates scratch, times the shadow-ray walks once, warms up
+        r2.render_device(d, buf.data_ptr(), buf.numel() * 4, stream)
+    torch.cuda.synchronize()
+    steps = max(2, min(args.steps, 5))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r2.render_device(d, buf.data_ptr(), buf.numel() * 4, stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = r2.stats()
+    r2.close()
+    return {"callers_splits_mrays_per_s": round(rays_per_step * steps / dt / 1e6, 2), "callers_splits_frame_ms": round(dt / steps * 1e3, 3),
+            "callers_splits_height": st["own_tree_height"]}
 
 
 def soup_figure(args, r, program, dev, stream):
