@@ -25,8 +25,8 @@
 //     are branch-free: write the child at the top, then add "some lane hit it" (SCC of s_cmp_lg_u64) to the pointer.  Depth:
 //     at most two waiting entries per level plus four at the frontier, 2 * height + 2 <= 62 (the build caps the height at 30);
 //   * two interior nodes per iteration when the stack holds two: their records are fetched together, halving the number of
-//     dependent memory round trips, which is what this walk waits for (scalar-cache hit rate 23 %, L2 61 % on the 1 M-triangle
-//     scene);
+//     dependent memory round trips, which is what this walk waits for (on the 1 M-triangle scene one record fetch in three
+//     hits the scalar cache and two in three of the rest the XCD's L2);
 //   * closest-hit walks (camera rays) keep the payload (t, u, v, primitive, hitType: RayPayload, acc.cl:55-61) in five VGPRs;
 //     two accepted hits with bit-equal t are settled by the reference's leaf order (SceneDev::rank8); any-hit walks (shadow
 //     rays: their callers read hitType only) drop a lane from `open` at its first accepted hit and end when `open` is empty.
