@@ -926,9 +926,10 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   sc.mats = (const Material*)ctx->d_mats;
   sc.lights = (const Lights*)ctx->d_lights;
   sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_mats = ctx->n_mats;
-  // Shadow rays as any-hit packets or per lane (traverse_packet_pairs_anyhit, lt_device.hpp): +20 % or -37 % of a frame
-  // depending on the scene, so each (scene, program) is timed once, on the first launch that can be repeated without
-  // changing the result, and the faster walk kept.  LT_SHADOW_PACKETS=0/1 forces one (tests, A/B measurements).
+  // Shadow rays as any-hit packets, per lane, or chosen per wavefront (traverse(), lt_device.hpp): which is fastest depends on
+  // the scene (wall: 17.4 ms as packets, 24.3 per lane; soup: the other way round), so each (scene, program, image geometry) is
+  // timed once, on the first launch that can be repeated without changing the result, and the fastest walk kept.
+  // LT_SHADOW_PACKETS=0/1/2 forces one (tests, A/B measurements).
   const char* spe = getenv("LT_SHADOW_PACKETS");
   const bool hasShadowRays = d->program == LT_PROGRAM_ACCUMULATOR || d->program == LT_PROGRAM_BASIC_LIGHTING;   // (the GI programs' kernels hold the per-lane walk only)
   // (keyed on the image geometry too: how coherent a wavefront's 64 shadow rays are depends on how large its 8x8 pixels are in

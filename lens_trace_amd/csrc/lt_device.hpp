@@ -29,7 +29,7 @@ typedef unsigned long long uint64_t;
 namespace lt {
 
 constexpr int kBlock = 64;         // one wavefront per workgroup: a finished wave frees its LDS and wave slot at once
-constexpr int kLdsStack = 32;      // most traversal-stack entries per lane held in LDS (the launch sizes LDS to the scene's BVH height)
+constexpr int kLdsStack = 32;      // most traversal-stack entries per lane held in LDS by the walks that keep an LDS stack (counting kernels, LDS-resident scenes)
 constexpr int kQueueStride = 64;   // dwords between work counters: one 256-byte line each.  (Eight per-XCD counters in one
                                    // cache line serialise every wave of the chip on one memory channel, 12 ns per work
                                    // item: 25 ms of a 2-million-item launch, whatever the items cost.  Taking several
@@ -593,17 +593,13 @@ struct Config {
 template <int PROGRAM, bool DEEP, bool STATS, bool SHADOW, bool LDSSCENE = false>
 __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgnore, int ignore, Hit& pl, Stack<DEEP>& st, Counters& c);
 
-// ---------------------------------------------------------------- packet traversal (camera rays)
-// The 64 camera rays of a wavefront (an 8x8 pixel square) visit almost the same nodes: on the 1 M-triangle scene at 4K
-// the union of their visited sets is 160 nodes against ~150 for any single ray.  When all of them are finite and share
-// their direction signs (every wave except those on the image's centre column/row) the wave walks the tree ONCE:
-//  * the node is fetched with scalar loads (one 32-byte s_load through the scalar cache instead of 64 lanes x 2 vector
-//    loads) and lands in SGPRs; each lane runs the same slab test against its own ray;
-//  * a lane "visits" a node iff it hit every ancestor's box -- a 64-bit lane mask travels with the node index on a
-//    wave-uniform stack (three dwords in the wave's LDS row) -- so each lane's set of tested nodes, the order in which it
-//    meets its leaves (near child first by the shared direction signs) and its work counters are exactly those of its own
-//    reference traversal; the wave descends while any lane hits;
-//  * no per-lane stack, no divergence inside the walk; the triangle test runs for the lanes that hit the leaf's box.
+// ---------------------------------------------------------------- packet traversal
+// The 64 camera rays of a wavefront (an 8x8 pixel square) visit almost the same nodes, so a wave whose rays are all finite walks
+// the tree ONCE: node data arrives through scalar loads, each lane runs the same slab test against its own ray, control flow is
+// scalar.  Two forms: traverse_packet (next) for the counting kernels -- over the caller's tree, one node per step, a 64-bit
+// lane mask ("this lane hit every ancestor") beside each node index on a wave-uniform stack, so that every lane's tested nodes,
+// the order of its leaves and its work counters are exactly those of its own reference traversal -- and packet_walk (further
+// down; lt_walk_asm.hpp) for everything else: over the backend's own tree, order-free, mask-free.
 typedef float F4v __attribute__((ext_vector_type(4)));
 typedef float F8v __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) F4v* ConstF4;   // constant address space: uniform loads become s_load
@@ -612,8 +608,6 @@ typedef float F16v __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) F16v* ConstF16;
 __device__ __forceinline__ float4 ld_const(ConstF4 p) { const F4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 
-// (This one-node-per-iteration form serves the counting kernels, whose work counters must be the reference's per lane; the
-// other kernels use traverse_packet_pairs below.)
 template <int PROGRAM, bool STATS>
 __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool nxU, bool nyU, bool nzU,
                                        Hit& pl, int* ldsWave, Counters& c) {

@@ -1,6 +1,6 @@
-"""GPU tests (-m gpu) of the two walks for shadow rays: 64 independent per-lane walks, or one any-hit packet walk per
-wavefront (traverse_packet_pairs_anyhit).  The callers of a shadow ray read only whether it hit, so both give the same
-pixels; which is faster depends on the scene, and the library times both once per (scene, program)."""
+"""GPU tests (-m gpu) of the walks for shadow rays: 64 independent per-lane walks, one any-hit packet walk per wavefront
+(packet_walk<..., ANYHIT>), or the choice between the two per wavefront.  The callers of a shadow ray read only whether it hit, so
+all give the same pixels; which is fastest depends on the scene, and the library times them once per (scene, program, image)."""
 import os
 
 import numpy as np
