@@ -1035,7 +1035,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       // per lane and level of the caller's tree in LDS; the others need the packet walks' two rows only (kPacketRows).
       ctx->lds_ref_bytes = (uint32_t)std::max(kPacketRows, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
       uint32_t lds = stats ? ctx->lds_ref_bytes : (uint32_t)kPacketRows * kBlock * sizeof(int);
-      if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = (uint32_t)std::max(kPacketRows, atoi(e)) * kBlock * sizeof(int);   // occupancy experiments
+      // (occupancy experiments: MORE rows than the launch needs, never fewer -- the counting kernels' per-lane stacks live there)
+      if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = std::max(lds, (uint32_t)std::max(0, std::min(160, atoi(e))) * (uint32_t)(kBlock * sizeof(int)));
       if (giWavefront) {
         SceneDev scGi = sc;
         scGi.shadowPackets = spe ? sc.shadowPackets : 0u;   // the pipeline's bounce stages cast incoherent shadow rays: per lane
