@@ -153,7 +153,7 @@ struct lt_hip_context {
   uint64_t gi_pixels = 0;
   uint32_t* d_giCtl = nullptr;
   // user programs (hipRTC), cached by path like the reference's programMap
-  struct UserProgram { hipModule_t module; hipFunction_t lds, deep, ldsStrict, deepStrict, ldsPortable, deepPortable; };
+  struct UserProgram { hipModule_t module; hipFunction_t lds, ldsStrict, ldsPortable; };   // one kernel per math flavour
   std::vector<UserProgram> user_programs;
   std::map<std::string, int> user_program_ids;
 };
@@ -307,9 +307,9 @@ static int compile_user_program(lt_hip_context* ctx, const std::string& path, in
   if (!g_hiprtc.load(err)) return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, err);
   const std::string src = "#define LT_USER_PROGRAM 1\n#include \"lt_kernel.hpp\"\n#line 1 \"" + path + "\"\n" + user.str() +
       "\n#define LT_USER_KERNEL(name, DEEP, DEVLIBM) extern \"C\" __global__ __launch_bounds__(64) void name(SceneDev sc, FrameParams fp, float* out, unsigned long long* stats, uint32_t* queues) { render_kernel_body<kUser, Config<DEEP, false, DEVLIBM>>(sc, fp, out, stats, queues); }\n"
-      "LT_USER_KERNEL(lt_user_kernel_lds, false, 2)\nLT_USER_KERNEL(lt_user_kernel_deep, true, 2)\n"
-      "LT_USER_KERNEL(lt_user_kernel_lds_strict, false, 1)\nLT_USER_KERNEL(lt_user_kernel_deep_strict, true, 1)\n"
-      "LT_USER_KERNEL(lt_user_kernel_lds_portable, false, 0)\nLT_USER_KERNEL(lt_user_kernel_deep_portable, true, 0)\n";
+      "LT_USER_KERNEL(lt_user_kernel_lds, false, 2)\n"
+      "LT_USER_KERNEL(lt_user_kernel_lds_strict, false, 1)\n"
+      "LT_USER_KERNEL(lt_user_kernel_lds_portable, false, 0)\n";
   void* prog = nullptr;
   if (g_hiprtc.createProgram(&prog, src.c_str(), "lt_user_program.hip", 0, nullptr, nullptr) != 0)
     return fail(ctx, LT_ERR_UNKNOWN_PROGRAM, "hiprtcCreateProgram failed");
@@ -335,11 +335,8 @@ static int compile_user_program(lt_hip_context* ctx, const std::string& path, in
   LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   LT_HIP_CHECK(ctx, hipModuleLoadData(&up.module, code.data()));
   LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.lds, up.module, "lt_user_kernel_lds"));
-  LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.deep, up.module, "lt_user_kernel_deep"));
   LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.ldsStrict, up.module, "lt_user_kernel_lds_strict"));
-  LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.deepStrict, up.module, "lt_user_kernel_deep_strict"));
   LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.ldsPortable, up.module, "lt_user_kernel_lds_portable"));
-  LT_HIP_CHECK(ctx, hipModuleGetFunction(&up.deepPortable, up.module, "lt_user_kernel_deep_portable"));
   ctx->user_programs.push_back(up);
   *out_program = LT_PROGRAM_USER_BASE + (int)ctx->user_programs.size() - 1;
   ctx->user_program_ids[path] = *out_program;
@@ -589,16 +586,14 @@ template <int PROGRAM>
 static void launch_program(const LaunchConfig& k, dim3 grid, uint32_t lds, hipStream_t s, const SceneDev& sc, const FrameParams& fp,
                            float* out, unsigned long long* st, uint32_t* queues) {
 #define LT_LAUNCH(D, S, M) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, Config<D, S, M>>), grid, dim3(kBlock), lds, s, sc, fp, out, st, queues)
+  // (DEEP -- LDS stack rows beyond kLdsStack spilled to scratch -- concerns the counting kernels only: the others keep no per-lane
+  // stack in LDS, whatever the height of the caller's tree)
   if (k.devlibm == 2) {     // the default flavour: the reference kernels as RendererOpenCL builds them
-    if (k.deep) { if (k.stats) LT_LAUNCH(true, true, 2); else LT_LAUNCH(true, false, 2); }
-    else { if (k.stats) LT_LAUNCH(false, true, 2); else LT_LAUNCH(false, false, 2); }
+    if (k.stats) { if (k.deep) LT_LAUNCH(true, true, 2); else LT_LAUNCH(false, true, 2); } else LT_LAUNCH(false, false, 2);
   } else if (k.devlibm == 1) {   // strict build of the reference kernels
-    if (k.deep) { if (k.stats) LT_LAUNCH(true, true, 1); else LT_LAUNCH(true, false, 1); }
-    else { if (k.stats) LT_LAUNCH(false, true, 1); else LT_LAUNCH(false, false, 1); }
-  } else if (k.deep) {
-    if (k.stats) LT_LAUNCH(true, true, 0); else LT_LAUNCH(true, false, 0);
+    if (k.stats) { if (k.deep) LT_LAUNCH(true, true, 1); else LT_LAUNCH(false, true, 1); } else LT_LAUNCH(false, false, 1);
   } else {
-    if (k.stats) LT_LAUNCH(false, true, 0); else LT_LAUNCH(false, false, 0);
+    if (k.stats) { if (k.deep) LT_LAUNCH(true, true, 0); else LT_LAUNCH(false, true, 0); } else LT_LAUNCH(false, false, 0);
   }
 #undef LT_LAUNCH
 }
@@ -1048,8 +1043,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         unsigned long long* statsPtr = ctx->d_stats;
         float* outPtr = out_launch;
         void* args[] = {(void*)&sc, (void*)&fp, (void*)&outPtr, (void*)&statsPtr, (void*)&queues};
-        const hipFunction_t fn = devlibm == 2 ? (deep ? up.deep : up.lds) : devlibm == 1 ? (deep ? up.deepStrict : up.ldsStrict)
-                                                                                            : (deep ? up.deepPortable : up.ldsPortable);
+        const hipFunction_t fn = devlibm == 2 ? up.lds : devlibm == 1 ? up.ldsStrict : up.ldsPortable;
         LT_HIP_CHECK(ctx, hipModuleLaunchKernel(fn, grid.x, 1, 1, kBlock, 1, 1, lds, s, args, nullptr));
       } else {
         // Time the three shadow-ray walks (packets, per lane, chosen per wavefront) once per (scene, program, image geometry), ahead
