@@ -643,7 +643,7 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   {
     const char* spe = getenv("LT_SHADOW_PACKETS");
     const int timed = ctx->shadow_mode[LT_PROGRAM_ACCUMULATOR];
-    scPrimary.shadowPackets = (CFG::kDeep ? 0u : spe ? (uint32_t)std::max(0, std::min(2, atoi(spe))) : (timed < 0 ? 1u : (uint32_t)timed));
+    scPrimary.shadowPackets = spe ? (uint32_t)std::max(0, std::min(2, atoi(spe))) : (timed < 0 ? 1u : (uint32_t)timed);
   }
   hipLaunchKernelGGL((lt_gi_primary_kernel<CFG>), dim3(gridA), dim3(kBlock), lds, s, scPrimary, fp, gp, queues);
   LT_HIP_CHECK(ctx, hipGetLastError());
@@ -652,7 +652,7 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   // eight waves share one copy.  LT_GI_LDS_SCENE=0 turns it off (A/B measurements).
   const uint64_t sceneLdsBytes = (uint64_t)ctx->n_nodes * 32 + (uint64_t)ctx->n_prims * 48;
   const char* le = getenv("LT_GI_LDS_SCENE");
-  const bool ldsScene = !CFG::kDeep && sceneLdsBytes <= 16384 && !(le && atoi(le) == 0);
+  const bool ldsScene = ctx->bvh_height <= kLdsStack && sceneLdsBytes <= 16384 && !(le && atoi(le) == 0);   // (its walks keep the LDS stack)
   gp.ldsRows = ctx->lds_ref_bytes / (kBlock * sizeof(int));   // (read by the multi-wave workgroups of the LDS-scene launches only)
   for (int d = 0; d < fp.giMaxDepth; d++) {
     if (ldsScene) {
@@ -777,8 +777,7 @@ static int launch_gi_sets(lt_hip_context* ctx, hipStream_t s, const SceneDev& sc
     }
     int rc;
 #define LT_GI(D, M) launch_gi_sample<Config<D, false, M>>(ctx, s, sc, fs, out, lds, giPixels, sample, k0, blendOut, fp.accumulateN, launches)
-    if (lc.deep) rc = lc.devlibm == 2 ? LT_GI(true, 2) : lc.devlibm == 1 ? LT_GI(true, 1) : LT_GI(true, 0);
-    else rc = lc.devlibm == 2 ? LT_GI(false, 2) : lc.devlibm == 1 ? LT_GI(false, 1) : LT_GI(false, 0);
+    rc = lc.devlibm == 2 ? LT_GI(false, 2) : lc.devlibm == 1 ? LT_GI(false, 1) : LT_GI(false, 0);   // (never a counting launch: no deep-tree form)
 #undef LT_GI
     if (rc) return rc;
   }
