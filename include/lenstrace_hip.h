@@ -182,7 +182,7 @@ int lt_hip_resolve_program(lt_hip_context* ctx, const char* kernel_file_path, in
  * (renderer_opencl.cpp:107-120), and in-place edits are honoured.
  * Derived at upload: the traversal-side triangle array (48-byte stride: A, B-A, C-A) and -- when every node's box encloses
  * its children's, which the reference's own builder guarantees -- the backend's OWN hierarchy over the caller's leaves
- * (binned surface-area heuristic, built on the host: ~1.5 s for a million triangles), the 64-byte records of its packet
+ * (binned surface-area heuristic, built on the host: ~0.1-0.4 s for a million triangles), the 64-byte records of its packet
  * walks and the reference's leaf order per direction-sign octant.  The caller's LinearBVHNode array stays resident and is
  * what the counting kernels (LT_RENDER_FLAG_STATS / _PIXEL_COUNTERS), rays with a non-finite component and scenes whose
  * boxes do not nest walk, in the reference's order.  Pixels do not depend on which hierarchy a ray walked

@@ -22,6 +22,8 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -238,20 +240,38 @@ inline int build(const void* nodes, uint32_t n_nodes, int maxHeight, int slack, 
   if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   if (n < 50000u) threads = 1;
   if (threads == 1) return build_range(nd, centroid.data(), order, out.data(), Range{0, n, 0, 0}, heightLimit);
-  // the top of the tree on this thread, the subtrees below it on all of them
-  std::vector<Range> parts;
-  int height = build_range(nd, centroid.data(), order, out.data(), Range{0, n, 0, 0}, heightLimit, &parts, n / (8u * (uint32_t)threads) + 1u);
-  std::sort(parts.begin(), parts.end(), [](const Range& a, const Range& b) { return a.end - a.start > b.end - b.start; });
-  std::atomic<size_t> next{0};
-  std::vector<int> heights((size_t)threads, 0);
+  // A queue of ranges: a large range gets its own node split by whoever takes it, and its two halves go back on the queue (one
+  // thread at the root, two below it, four ...); a range of at most n / (8 threads) leaves is built to the bottom by one thread.
+  // Every split is the one the single-threaded build makes, so the tree does not depend on the thread count.
+  const uint32_t whole = n / (8u * (uint32_t)threads) + 1u;
+  std::mutex mx;
+  std::condition_variable cv;
+  std::vector<Range> queue{Range{0, n, 0, 0}};
+  int busy = 0, height = 0;
+  auto worker = [&]() {
+    std::unique_lock<std::mutex> lk(mx);
+    for (;;) {
+      cv.wait(lk, [&]() { return !queue.empty() || busy == 0; });
+      if (queue.empty()) return;   // (nothing queued and nobody who could queue anything: done)
+      const Range r = queue.back();
+      queue.pop_back();
+      busy++;
+      lk.unlock();
+      std::vector<Range> kids;
+      int h;
+      if (r.end - r.start <= whole) h = build_range(nd, centroid.data(), order, out.data(), r, heightLimit);
+      else h = build_range(nd, centroid.data(), order, out.data(), r, heightLimit, &kids, r.end - r.start - 1u);   // this node only
+      lk.lock();
+      height = std::max(height, h);
+      for (const Range& k : kids) queue.push_back(k);
+      busy--;
+      cv.notify_all();
+    }
+  };
   std::vector<std::thread> pool;
-  for (int t = 0; t < threads; t++)
-    pool.emplace_back([&, t]() {
-      for (size_t k = next.fetch_add(1); k < parts.size(); k = next.fetch_add(1))
-        heights[(size_t)t] = std::max(heights[(size_t)t], build_range(nd, centroid.data(), order, out.data(), parts[k], heightLimit));
-    });
+  for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+  worker();
   for (std::thread& th : pool) th.join();
-  for (int h : heights) height = std::max(height, h);
   return height;
 }
 
