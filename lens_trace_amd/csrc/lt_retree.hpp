@@ -25,6 +25,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -237,7 +238,10 @@ inline int build(const void* nodes, uint32_t n_nodes, int maxHeight, int slack, 
   out.assign(2 * (size_t)n - 1, Node{});
   // the top of the tree on this thread until there are enough independent subtrees for the others (a pre-order subtree of k
   // leaves owns out[node, node + 2k - 1) and order[start, end): nothing is shared)
-  if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (threads <= 0) {
+    const char* e = getenv("LT_RETREE_THREADS");
+    threads = e ? std::max(1, std::min(64, atoi(e))) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  }
   if (n < 50000u) threads = 1;
   if (threads == 1) return build_range(nd, centroid.data(), order, out.data(), Range{0, n, 0, 0}, heightLimit);
   // A queue of ranges: a large range gets its own node split by whoever takes it, and its two halves go back on the queue (one

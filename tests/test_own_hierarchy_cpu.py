@@ -67,6 +67,17 @@ def test_own_hierarchy_keeps_the_leaves_and_nests(name, slack):
         assert own.tobytes() == nodes.tobytes()
 
 
+def test_the_tree_does_not_depend_on_the_thread_count(monkeypatch):
+    s = synth.heightfield_wall(180).validate()            # 64 800 leaves: above the size from which the build goes parallel
+    nodes = view(s)
+    trees = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("LT_RETREE_THREADS", threads)
+        h, own, _ = C.own_hierarchy(nodes, s.n_prims, 2)
+        trees.append((h, own.tobytes()))
+    assert trees[0] == trees[1] == trees[2]
+
+
 def test_surface_area_sum_drops():
     """Without clipping against the closest hit the expected number of nodes a random ray visits is the sum of the nodes' surface
     areas over the root's: what the build minimises."""
