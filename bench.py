@@ -112,6 +112,9 @@ def parse():
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--bvh", default="median", choices=["median", "sah"], help="split rule of the scene's BVH (same 32-byte node layout): "
                     "the reference's median split (default, the headline) or this backend's binned SAH")
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2], help="steps in flight: 2 = step k+1 is enqueued (its own "
+                    "context, stream and buffers) while step k drains and is gathered; every one of the K steps starts and ends inside "
+                    "the timed region.  0 (default) = 1 on one GPU, 2 on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-soup", action="store_true", help="skip the second figure (config 4's incoherent triangle-soup variant)")
     return ap.parse_args()
@@ -199,19 +202,42 @@ def main():
     # every rank's stack is padded to the largest one so that the gather is uniform
     per_rank = my_floats if world == 1 else plan.floats_per_rank
     assert my_floats <= per_rank
-    mine = torch.zeros(per_rank, dtype=torch.float32, device=dev)
-    # the root receives every rank's stack straight into its row of `stack` (rows are contiguous views: no staging copy)
-    stack = torch.empty((world, per_rank), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
-    gathered = [stack[i] for i in range(world)] if stack is not None else None
-    image = torch.empty((H, W, D), dtype=torch.float32, device=dev) if rank == 0 else None
-    stream = torch.cuda.current_stream().cuda_stream
+    # A launch ends with a drain -- the last squares' dependent chains, ~0.5 ms during which most of the chip idles -- and a rank's
+    # gather and untile leave it idle too.  With two steps in flight, step k+1 (second context: its own copy of the scene, scratch,
+    # stream and output buffers) fills the chip while step k drains and is gathered.  Slot = what one in-flight step owns.
+    class Slot:
+        pass
+    if args.in_flight == 0:
+        # one GPU: a 17 ms launch gains 0.6 % from overlapping its drain, and its HIP-event duration would then include the
+        # neighbour's start; several GPUs: a share's launch is a few ms, a third of it drain, and the gather idles the chip
+        args.in_flight = 1 if world == 1 else 2
+    slots = []
+    for i in range(args.in_flight):
+        sl = Slot()
+        sl.r = r if i == 0 else RendererHIP(local_rank)
+        if i > 0:
+            sl.r.set_scene(scene)
+        sl.tstream = torch.cuda.current_stream() if args.in_flight == 1 else torch.cuda.Stream(device=dev)
+        sl.stream = sl.tstream.cuda_stream
+        sl.mine = torch.zeros(per_rank, dtype=torch.float32, device=dev)
+        # the root receives every rank's stack straight into its row of `stack` (rows are contiguous views: no staging copy)
+        sl.stack = torch.empty((world, per_rank), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+        sl.gathered = [sl.stack[j] for j in range(world)] if sl.stack is not None else None
+        sl.image = torch.empty((H, W, D), dtype=torch.float32, device=dev) if rank == 0 else None
+        sl.pending = False
+        slots.append(sl)
+    torch.cuda.synchronize()
+    stream = slots[0].stream
 
-    def step(dd):
-        r.render_device(dd, mine.data_ptr(), per_rank * 4, stream)
-        if world > 1:
-            dist.gather(mine, gathered, dst=0)
-            if rank == 0:
-                r.untile(stack.data_ptr(), per_rank, world, W, H, D, plan.tile_w, plan.tile_h, image.data_ptr(), stream)
+    def step(dd, sl=None):
+        sl = sl or slots[0]
+        with torch.cuda.stream(sl.tstream):
+            sl.r.render_device(dd, sl.mine.data_ptr(), per_rank * 4, sl.stream)
+            if world > 1:
+                dist.gather(sl.mine, sl.gathered, dst=0)
+                if rank == 0:
+                    sl.r.untile(sl.stack.data_ptr(), per_rank, world, W, H, D, plan.tile_w, plan.tile_h, sl.image.data_ptr(), sl.stream)
+        sl.pending = True
 
     # ---- reference-algorithm work counts of this rank's share (one untimed pass with device atomics) ----
     step(desc(stats=True))
@@ -226,29 +252,44 @@ def main():
     # (one launch per sample, or ONE for all samples when the library fuses them: lt_capi.hip, render_on_stream)
     my_alg_bytes_per_step = 32.0 * st["node_visits"] + 76.0 * st["tri_tests"] + 36.0 * st["pixels"] * args.spp
 
-    # set-up, not a step: the first timed-shape call allocates the library's scratch memory (sample images of the fused
-    # launch) and, under RCCL, opens the point-to-point channels of the gather
-    step(d)
-    for _ in range(args.warmup):
-        step(d)
+    # set-up, not a step: the first timed-shape call of a context allocates the library's scratch memory (sample images of the
+    # fused launch), times the shadow-ray walks once and, under RCCL, opens the point-to-point channels of the gather
+    for sl in slots:
+        step(d, sl)
+        torch.cuda.synchronize()
+    for k in range(args.warmup):
+        step(d, slots[k % len(slots)])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     own_tree = (r.stats()["own_tree_height"], r.stats()["own_tree_ms"])
+    for sl in slots:
+        sl.pending = False
     t0 = time.perf_counter()
     shadow_walk = -1
     kernel_ms = 0.0
     render_ms = 0.0     # lt_render_kernel alone (kernel_ms also holds the running-mean kernel behind each fused launch)
     launches = 0
-    for _ in range(args.steps):
-        step(d)
-        # the per-call HIP events sit on the launch stream; reading them waits for this step's kernels only
-        s = r.stats()
-        shadow_walk = s["shadow_packets"]
-        kernel_ms += s["kernel_ms"]
-        render_ms += s["render_ms"]
-        launches += s["kernel_launches"]
+
+    def collect(sl):
+        # the per-call HIP events sit on the launch stream; reading them waits for that step's kernels only
+        nonlocal shadow_walk, kernel_ms, render_ms, launches
+        st_ = sl.r.stats()
+        shadow_walk = st_["shadow_packets"]
+        kernel_ms += st_["kernel_ms"]
+        render_ms += st_["render_ms"]
+        launches += st_["kernel_launches"]
+        sl.pending = False
+
+    for k in range(args.steps):
+        sl = slots[k % len(slots)]
+        if sl.pending:
+            collect(sl)     # (the step that used this slot before: at most len(slots) steps are ever in flight)
+        step(d, sl)
+    for sl in slots:
+        if sl.pending:
+            collect(sl)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -296,7 +337,7 @@ def main():
                        "triangles": scene.n_prims, "bvh_nodes": scene.n_nodes, "bvh_split": args.bvh, "width": W, "height": H, "spp": args.spp,
                        "rays_per_frame": rays_total, "node_visits_per_ray": nodes_total / rays_total,
                        "tri_tests_per_ray": tris_total / rays_total, "kernel_only_mrays_per_s": round(rays_total * args.steps / kernel_s / 1e6, 2),
-                       "frame_ms": round(ms_per_step, 3),
+                       "frame_ms": round(ms_per_step, 3), "steps_in_flight": args.in_flight,
                        # which of its three (pixel-identical) walks the library timed fastest for this scene's shadow rays
                        "shadow_ray_walk": SHADOW_WALKS.get(shadow_walk, "not timed"),
                        # the backend's own hierarchy over the caller's leaves: height, host build time at set_scene (not in any step)
@@ -316,6 +357,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    for sl in slots[1:]:
+        sl.r.close()
     r.close()
 
 

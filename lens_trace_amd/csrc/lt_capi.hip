@@ -1063,9 +1063,12 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         if (calibrate) {
           for (hipEvent_t& e : ctx->cal_ev) if (!e) LT_HIP_CHECK(ctx, hipEventCreate(&e));
           FrameParams f1 = fp;
-          // (up to four of the call's frames: one frame alone ends when its slowest squares do -- the image's centre row and
-          // column, whose non-finite rays walk the caller's tree -- whatever the other 130 000 do)
-          f1.fusedFrames = std::min(fp.fusedFrames, 4u);
+          // (enough of the call's frames for about four 4K images' worth of squares: a short launch ends when its slowest squares
+          // do -- the image's centre row and column, whose non-finite rays walk the caller's tree -- whatever the others do, and
+          // an eighth of a frame -- one GPU's share of eight -- timed that way picked the per-lane walk where packets are 30 %
+          // faster)
+          const uint32_t enough = (uint32_t)std::min<uint64_t>(1024u, (4ull * 129600ull + fp.totalSquares - 1) / std::max(1u, fp.totalSquares));
+          f1.fusedFrames = std::min(fp.fusedFrames, std::max(4u, enough));
           const dim3 g1((uint32_t)std::min<uint64_t>(nblocks, resident));
           static const uint32_t kOrder[3] = {1u, 0u, 2u};
           for (int pass = 0; pass < 6; pass++) {
