@@ -9,6 +9,8 @@ rank 0 per frame.
 
 A "step" is one complete frame of the workload: all 16 sample launches of this rank's tiles, the gather (N > 1)
 and the root-side untile.  Timed region: barrier + synchronize, K steps, synchronize + barrier; MAX over ranks.
+On several GPUs two steps are in flight (--in-flight): step k+1 is enqueued -- its own context, stream and buffers -- while step k
+drains and is gathered; all K steps start and end inside the timed region.
 Scene and framebuffers are resident in HBM before the timed region starts.  Rank 0 prints one JSON line.
 
 `roofline` describes the dominant kernel (lt_render_kernel: one launch renders all samples of a step).  The kernel is not
