@@ -24,7 +24,7 @@ RENDER_FLAG_STRICT_MATH = 16
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",
            "lt_hip_resolve_program",
            "lt_hip_set_scene", "lt_hip_output_floats", "lt_hip_render", "lt_hip_render_device", "lt_hip_untile",
-           "lt_hip_synchronize", "lt_hip_get_stats", "lt_hip_own_hierarchy"]
+           "lt_hip_synchronize", "lt_hip_get_stats", "lt_hip_own_hierarchy", "lt_hip_own_quantised"]
 
 
 class RenderDesc(ctypes.Structure):
@@ -93,6 +93,8 @@ def load():
     L.lt_hip_synchronize.argtypes = [vp, vp]
     L.lt_hip_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     for name in EXPORTS:
+        if not hasattr(L, name) and os.environ.get("LT_HIP_LIBRARY"):
+            continue      # (an older build of the library loaded for an A/B measurement, tests/tools/ab_libs.sh)
         if name not in ("lt_hip_last_error",):
             getattr(L, name).restype = i32
     if L.lt_hip_abi_version() != 4:
@@ -124,3 +126,20 @@ def own_hierarchy(nodes, n_prims=0, height_slack=2, want_ranks=False):
     if h < 0:
         return -1, None, None
     return h, out, ranks
+
+
+OWN16_DTYPE = [("q", "<u2", (6,)), ("link", "<u4")]   # lo.x lo.y lo.z hi.x hi.y hi.z on the grid; escape index or 0x80000000 | primitive
+
+
+def own_quantised(own_nodes):
+    """lt_hip_own_quantised (host only): (origin[3], step[3], records as an OWN16_DTYPE array) of an own hierarchy."""
+    import numpy as np
+    own_nodes = np.ascontiguousarray(own_nodes)
+    frame = np.zeros(6, dtype=np.float32)
+    out = np.zeros(len(own_nodes), dtype=OWN16_DTYPE)
+    assert out.dtype.itemsize == 16
+    rc = load().lt_hip_own_quantised(own_nodes.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(own_nodes.nbytes),
+                                     frame.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(out.nbytes))
+    if rc:
+        raise LensTraceError(LT_ERR_BAD_SCENE, "lt_hip_own_quantised failed")
+    return frame[:3].copy(), frame[3:].copy(), out

@@ -2,6 +2,7 @@
 // Host side of what the reference does in RendererOpenCL::render() (src/opencl/renderer_opencl.cpp:56-153).
 #include "lt_kernel.hpp"
 #include "lt_retree.hpp"
+#include "lt_own16.hpp"
 
 #include "../../include/lenstrace_hip.h"
 
@@ -36,14 +37,7 @@ __global__ void lt_retile_kernel(const float* __restrict__ prims, float4* __rest
 //                    a reference = the child's index, with bit 31 set when the child is a leaf;
 //   leaf i:          [A, e1 = B - A, e2 = C - A of its triangle (lt_retile_kernel's arithmetic)][the leaf's own box, bit for
 //                    bit][the primitive offset]: what the reference's leaf test needs, in one scalar load.
-__device__ __forceinline__ float lt_outwards(float b, bool up) {
-  const float t = up ? b + __builtin_fabsf(b) * 0x1p-21f : b - __builtin_fabsf(b) * 0x1p-21f;
-  uint32_t u = __float_as_uint(t);
-  if ((u & 0x7fffffffu) == 0u) return __uint_as_float((up ? 0u : 0x80000000u) | 1u);    // +-0 -> the smallest denormal of that side
-  const bool away = (t > 0.0f) == up;   // moving away from zero = the next larger magnitude
-  u = away ? u + 1u : u - 1u;
-  return __uint_as_float(u);
-}
+__device__ __forceinline__ float lt_outwards(float b, bool up) { return lt_own16::outwards(b, up); }
 __global__ void lt_own_pair_kernel(const float4* __restrict__ nodes, const float* __restrict__ prims, float4* __restrict__ pairs, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -64,6 +58,23 @@ __global__ void lt_own_pair_kernel(const float4* __restrict__ nodes, const float
     pairs[4 * (size_t)i + 2 * k] = make_float4(lt_outwards(ca.x, false), lt_outwards(ca.y, false), lt_outwards(ca.z, false), lt_outwards(ca.w, true));
     pairs[4 * (size_t)i + 2 * k + 1] = make_float4(lt_outwards(cb.x, true), lt_outwards(cb.y, true), __uint_as_float(child[k] | (leaf ? 0x80000000u : 0u)), 0.0f);
   }
+}
+
+// The per-lane walks' 16-byte nodes (SceneDev::own16, traverse_own_lane), from the own tree in its threaded form (an interior
+// node's `off` = its escape index): the node's box on a 16-bit grid over the scene's bounds, rounded outwards -- q such that, in
+// real arithmetic, O + ql S <= lo - 8u|lo| and O + qh S >= hi + 8u|hi| (lt_own16.hpp: `outwards` gives 9u; the sums are formed
+// in double: exact, or within 2^-53 of the scene's extent, far inside the spare factor of two of the walk's margin) -- and the
+// link: the escape index, or 0x80000000 | primitive offset for a leaf.  *bad is set when a bound falls off the grid (the host
+// sizes the grid from the root's box with room to spare; the scene then simply gets no hierarchy of the backend's own).
+struct Own16Frame { float O[3], S[3]; };
+__global__ void lt_own16_kernel(const float4* __restrict__ nodes, uint4* __restrict__ out, uint32_t n, Own16Frame fr, uint32_t* __restrict__ bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = nodes[2 * (size_t)i], b = nodes[2 * (size_t)i + 1];
+  const float lo[3] = {a.x, a.y, a.z}, hi[3] = {a.w, b.x, b.y};
+  lt_own16::Rec r;
+  if (!lt_own16::node_record(lo, hi, __float_as_uint(b.z), (__float_as_uint(b.w) & 0xffffu) != 0u, fr.O, fr.S, r)) atomicOr(bad, 1u);
+  out[i] = make_uint4(r.x, r.y, r.z, r.w);
 }
 
 // Gathered per-rank tile stacks -> row-major image (root side of the one gather per frame).
@@ -118,6 +129,8 @@ struct lt_hip_context {
   void *d_nodes = nullptr, *d_tris = nullptr, *d_prims = nullptr, *d_mats = nullptr, *d_lights = nullptr;
   void *d_nodes2 = nullptr, *d_pairs2 = nullptr;   // the backend's own tree over the scene's leaves (lt_retree.hpp), or null
   void* d_rank8 = nullptr;                         // with it: the reference's leaf order per direction-sign octant (SceneDev::rank8)
+  void* d_own16 = nullptr;                         // ... and the per-lane walks' 16-byte nodes (SceneDev::own16) on the grid q16_origin + q * q16_step
+  float q16_origin[3] = {0, 0, 0}, q16_step[3] = {1, 1, 1};
   int height2 = 0;                                 // its height
   uint32_t n_nodes2 = 0;
   float retree_ms = 0.0f;                          // host time of its build
@@ -208,7 +221,7 @@ extern "C" int lt_hip_create(int device_index, lt_hip_context** out_ctx) {
 }
 
 static void free_scene(lt_hip_context* ctx) {
-  for (void** p : {&ctx->d_nodes, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights, &ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_rank8}) {
+  for (void** p : {&ctx->d_nodes, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights, &ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_rank8, &ctx->d_own16}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -454,6 +467,23 @@ extern "C" int lt_hip_own_hierarchy(const void* nodes, uint64_t node_bytes, int 
   return h;
 }
 
+extern "C" int lt_hip_own_quantised(const void* own_nodes, uint64_t node_bytes, float* origin_step, void* out_records, uint64_t out_bytes) {
+  if (!own_nodes || !origin_step || !out_records || node_bytes == 0 || node_bytes % 32 || node_bytes > 0xffffffffull) return -1;
+  const uint32_t n = (uint32_t)(node_bytes / 32);
+  if (out_bytes < (uint64_t)n * 16) return -1;
+  const lt_retree::Node* src = (const lt_retree::Node*)own_nodes;
+  for (uint32_t i = 0; i < n; i++)   // (a pre-order tree: children behind their parent, in range)
+    if (src[i].cnt == 0 && (i + 1 >= n || src[i].off <= (int32_t)i + 1 || (uint32_t)src[i].off >= n)) return -1;
+  std::vector<lt_retree::Node> own(src, src + n);
+  lt_retree::thread(own);
+  for (int a = 0; a < 3; a++) lt_own16::frame(own[0].lo[a], own[0].hi[a], origin_step[a], origin_step[3 + a]);
+  lt_own16::Rec* out = (lt_own16::Rec*)out_records;
+  bool ok = true;
+  for (uint32_t i = 0; i < n; i++)
+    ok = lt_own16::node_record(own[i].lo, own[i].hi, (uint32_t)own[i].off, own[i].cnt != 0, origin_step, origin_step + 3, out[i]) && ok;
+  return ok ? 0 : -1;
+}
+
 extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims,
                                 uint64_t prim_bytes, const void* materials, uint64_t material_bytes, const void* lights,
                                 uint64_t light_bytes) {
@@ -519,14 +549,36 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
                          (const float*)ctx->d_prims, (float4*)ctx->d_pairs2, n2);
       LT_HIP_CHECK(ctx, hipGetLastError());
       LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-      lt_retree::thread(own);   // (the pair records are made: now the form the stackless per-lane walks read)
+      lt_retree::thread(own);   // (the pair records are made: now the form the stackless per-lane walks want, escape links)
       LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_nodes2, own.data(), (size_t)n2 * 32, hipMemcpyHostToDevice));
-      ctx->n_nodes2 = n2;
-      ctx->height2 = h2;
-      std::vector<uint32_t> rank8;
-      lt_retree::reference_order(nodes, n_prims, rank8);
-      LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_rank8, rank8.size() * sizeof(uint32_t)));
-      LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_rank8, rank8.data(), rank8.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      // ... which read it as 16-byte quantised nodes (lt_own16.hpp); the 32-byte form is not kept
+      Own16Frame fr;
+      for (int a = 0; a < 3; a++) lt_own16::frame(own[0].lo[a], own[0].hi[a], fr.O[a], fr.S[a]);
+      LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_own16, (size_t)n2 * 16 + 32));   // (32 bytes in front: the grid, read by the walks themselves)
+      {
+        const float head[8] = {fr.O[0], fr.O[1], fr.O[2], 0.0f, fr.S[0], fr.S[1], fr.S[2], 0.0f};
+        LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_own16, head, sizeof(head), hipMemcpyHostToDevice));
+      }
+      LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long), ctx->stream));
+      hipLaunchKernelGGL(lt_own16_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2, (uint4*)ctx->d_own16 + 2, n2, fr,
+                         (uint32_t*)ctx->d_stats);
+      LT_HIP_CHECK(ctx, hipGetLastError());
+      uint32_t bad = 0;
+      LT_HIP_CHECK(ctx, hipMemcpyAsync(&bad, ctx->d_stats, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+      LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      LT_HIP_CHECK(ctx, hipFree(ctx->d_nodes2));
+      ctx->d_nodes2 = nullptr;
+      if (bad) {   // (cannot happen for a grid sized from the root's box; the scene then walks the caller's tree)
+        for (void** p : {&ctx->d_pairs2, &ctx->d_own16}) { (void)hipFree(*p); *p = nullptr; }
+      } else {
+        for (int a = 0; a < 3; a++) { ctx->q16_origin[a] = fr.O[a]; ctx->q16_step[a] = fr.S[a]; }
+        ctx->n_nodes2 = n2;
+        ctx->height2 = h2;
+        std::vector<uint32_t> rank8;
+        lt_retree::reference_order(nodes, n_prims, rank8);
+        LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_rank8, rank8.size() * sizeof(uint32_t)));
+        LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_rank8, rank8.data(), rank8.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      }
       ctx->retree_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
   }
@@ -911,7 +963,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
 
   SceneDev sc;
   sc.nodes = (const float4*)ctx->d_nodes;
-  sc.ownNodes = (const float4*)ctx->d_nodes2;
+  sc.own16 = ctx->d_own16 ? (const uint4*)ctx->d_own16 + 2 : nullptr;   // (behind the 32-byte grid header)
   sc.ownPairs = (const float4*)ctx->d_pairs2;
   sc.rank8 = (const uint32_t*)ctx->d_rank8;
   sc.nOwn = ctx->d_rank8 ? ctx->n_nodes2 : 0u;
@@ -1218,7 +1270,7 @@ extern "C" int lt_hip_get_stats(lt_hip_context* ctx, lt_hip_stats* out) {
   *out = ctx->last;
   out->scene_uploads = ctx->scene_uploads;
   out->scene_reused = ctx->scene_reused;
-  out->own_tree_height = ctx->d_nodes2 ? ctx->height2 : -1;
+  out->own_tree_height = ctx->d_rank8 ? ctx->height2 : -1;
   out->own_tree_ms = ctx->retree_ms;
   return LT_OK;
 }

@@ -62,16 +62,25 @@ struct SceneDev {
   const float4* nodes;
   // The backend's own tree over the caller's leaves (lt_retree.hpp: same leaves, same boxes, binned-SAH hierarchy), walked by
   // every finite ray of the non-counting kernels; null (and rank8 null) when the scene has none: its boxes do not nest.
-  const float4* ownNodes;   // 32-byte nodes in the caller's layout, an interior node's escape index in place of its second child
   const float4* ownPairs;   // 64-byte records of the packet walks (lt_own_pair_kernel)
   // With it, for the closest-hit walks: rank8[8 * primitive + octant] = position of the primitive's leaf in the REFERENCE's
   // depth-first order for rays of that direction-sign octant.  intersectTriangle keeps the first of two hits with equal t
   // (`t < payload.t`, acc.cl:104); a walk that meets the leaves in another order keeps the one with the lower rank.  Null
   // when the walks follow the caller's tree in the reference's order themselves.
   const uint32_t* rank8;
-  uint32_t nOwn;            // nodes of the own tree, whose interior nodes hold their ESCAPE index where the caller's hold the second
-                            // child (lt_retree.hpp: the node that follows the subtree in pre-order, nOwn at the end): the per-lane
-                            // walks over it need no stack (traverse_own_lane)
+  uint32_t nOwn;            // nodes of the own tree
+  // The own tree as the per-lane walks read it (traverse_own_lane): ONE 16-byte record per node -- the node's box quantised to
+  // 16 bits per bound on a grid over the scene's bounds, rounded outwards (q16Origin + q * q16Step per axis), and a link: an
+  // interior node's ESCAPE index (the node that follows its subtree in pre-order, nOwn at the end: the walk needs no stack), a
+  // leaf's primitive offset with bit 31 set.  A per-lane walk is 64 different addresses per visited node, and what it saturates
+  // is the vector-memory address path -- one lane-address per clock and CU (tools/probes/gather_calib.hip) -- so a visit that is
+  // one global_load_dwordx4 instead of the two of a 32-byte node takes half the time.  Legal for the reason the packet walks'
+  // pushed-out boxes are (lt_walk_asm.hpp): only a LEAF's own box needs the reference's exact test, and that comes from the
+  // leaf's 64-byte record in ownPairs.  (A half-precision box was tried in round 2 and lost: a half carries 11 bits of the
+  // COORDINATE; 16 bits of the scene's extent are 32 times finer around coordinate 5 of a 10-unit scene.)
+  // The grid sits in front of the records: own16[-2] = (origin.xyz, -), own16[-1] = (step.xyz, -), fetched by scalar loads at the
+  // start of a walk (kernel arguments occupy SGPRs for the whole kernel, and the render kernels have none to spare).
+  const uint4* own16;
   const float4* tris;
   const float* prims;       // 19 floats per primitive
   const Material* mats;
@@ -90,6 +99,13 @@ struct SceneDev {
                             // own ray's length of the first lane's origin (one surface patch looking at one light), else per lane
 };
 
+typedef float F4v __attribute__((ext_vector_type(4)));
+typedef float F8v __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) F4v* ConstF4;   // constant address space: uniform loads become s_load
+typedef const __attribute__((address_space(4))) F8v* ConstF8;
+typedef float F16v __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) F16v* ConstF16;
+__device__ __forceinline__ float4 ld_const(ConstF4 p) { const F4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 typedef float LdsVec4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) LdsVec4* LdsF4;   // (a plain vector type: HIP's float4 class cannot be read through an address-space pointer)
 __device__ __forceinline__ float4 ld_lds(LdsF4 p) { const LdsVec4 v = *p; return make_float4(v.x, v.y, v.z, v.w); }
@@ -546,39 +562,95 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
 // The per-lane walk over the backend's own tree (finite rays of the non-counting kernels; lt_retree.hpp says why any order over
 // any enclosing hierarchy finds the reference's set of leaves).  No stack: the tree is in pre-order, the left child follows its
 // parent, and an interior node carries its escape index -- where the walk continues when the node's box is missed or its subtree
-// is done -- so a step is "fetch, slab test, pick i + 1 or the escape".  Leaves are noted and tested at the top of the next
-// step, behind the issue of its loads, as in the stack walk above.  Closest-hit walks settle equal-t ties with the reference's
-// leaf order (SceneDev::rank8); any-hit walks (shadow rays: their callers read hitType only) stop at the first accepted hit.
+// is done -- so a step is "fetch 16 bytes, conservative slab test, pick i + 1 or the escape".  A leaf whose quantised box is
+// hit is only noted; its 64-byte record (the leaf's own box bit for bit, the re-tiled triangle, the primitive offset:
+// lt_own_pair_kernel) is fetched at the top of the next step, behind the issue of that step's node load, and gets the
+// reference's own slab test and triangle test.  Closest-hit walks settle equal-t ties with the reference's leaf order
+// (SceneDev::rank8); any-hit walks (shadow rays: their callers read hitType only) stop at the first accepted hit.
+//
+// The conservative test on a quantised box [O + ql S, O + qh S] (per axis; O, S floats taken as exact reals; the build checks in
+// double that O + ql S <= lo - 8u|lo| and O + qh S >= hi + 8u|hi| for the node's true box, u = 2^-24).  Per lane, once per ray:
+//     sI = fl(S inv),  p = fl(o inv),  c = fma(O, inv, -p),  m = 2^-21 (E |inv| + |O inv| + |p|) + 2^-140,  E = 65535 S   (per axis)
+//     cN = fl(c - m),  cF = fl(c + m),  (qn, qf) = (ql, qh) where inv >= 0, (qh, ql) where inv < 0
+// and per node     tN = max_a fma(qn_a, sI_a, cN_a),  tF = min_a fma(qf_a, sI_a, cF_a),  accept iff tF >= max(tN, 0+).
+// It accepts whenever the reference's test (acc.cl:113-130) accepts the node's true box (hence any box inside it).  Per axis, inv > 0
+// (the other sign mirrors): t(q) := fma(q, sI, c) = (O + q S - o) inv + D with |D| <= u (q S |inv| + |o inv| + |O inv - p| + |t|)
+// (1 + 2u) <= 2.02 u K, K = E |inv| + |O inv| + |p| -- the roundings of sI, p, c and of the fma itself; the reference computes
+// tN_ref = fl(fl(lo - o) inv) >= (lo - o) inv - 2.01 u (|lo| + |o|) |inv|.  With O + ql S <= lo - 8u |lo|:
+//     t(ql) - tN_ref <= -8u |lo inv| + 2.01 u |lo inv| + 2.01 u |o inv| + |D| <= 4.1 u K,
+// and folding the margin into the constant costs one more rounding, u (|c| + m) <= 1.1 u K: fma(ql, sI, cN) <= tN_ref as soon as
+// m >= 5.2 u K; m = 2^-21 K = 8 u K.  Symmetrically fma(qh, sI, cF) >= tF_ref.  So tN <= tN_ref and tF >= tF_ref axis by axis, and
+// tF_ref >= max(tN_ref, 0+) implies tF >= max(tN, 0+).  The margins are PER AXIS on purpose: an axis the ray is almost parallel
+// to has a huge |inv| and hence huge absolute errors, but they concern that axis' own (equally huge) entry and exit distances
+// only -- one margin for all three axes (the form the packet walks use, where origins are small multiples of the directions)
+// makes such a ray accept every box within 2^-19 E |inv| of its path: a handful of rays per million that walk half the tree and
+// hold their wavefronts' launch back (measured: the 1 M-triangle wall's bounce stages twice as long).  All magnitudes stay below
+// 2^102 (|o|, |O|, E < 2^41, |inv| < 2^60: packet_ray_ok, checked per wave; the scene's bounds below 2^40:
+// lt_retree::collect_leaves), gradual underflow adds at most 2^-148 per operation: the 2^-140.
+// tests/test_own_hierarchy_cpu.py tries the inequality on random and grazing rays against quantised boxes made by the build's
+// own arithmetic.
+struct Own16Ray { float sx, sy, sz, nx, ny, nz, fx, fy, fz; };   // sI; cN; cF
+__device__ __forceinline__ Own16Ray own16_ray(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz) {
+  Own16Ray r;
+  const F8v fr = *(ConstF8)((unsigned long long)sc.own16 - 32ull);   // origin.xyz - step.xyz -
+  const float px = ray.o.x * ix, py = ray.o.y * iy, pz = ray.o.z * iz;
+  r.sx = fr.s4 * ix; r.sy = fr.s5 * iy; r.sz = fr.s6 * iz;
+  const float cx = __builtin_fmaf(fr.s0, ix, -px), cy = __builtin_fmaf(fr.s1, iy, -py), cz = __builtin_fmaf(fr.s2, iz, -pz);
+  const float mx = (__builtin_fabsf(65535.0f * fr.s4 * ix) + __builtin_fabsf(fr.s0 * ix) + __builtin_fabsf(px)) * 0x1p-21f + 0x1p-140f;
+  const float my = (__builtin_fabsf(65535.0f * fr.s5 * iy) + __builtin_fabsf(fr.s1 * iy) + __builtin_fabsf(py)) * 0x1p-21f + 0x1p-140f;
+  const float mz = (__builtin_fabsf(65535.0f * fr.s6 * iz) + __builtin_fabsf(fr.s2 * iz) + __builtin_fabsf(pz)) * 0x1p-21f + 0x1p-140f;
+  r.nx = cx - mx; r.ny = cy - my; r.nz = cz - mz;
+  r.fx = cx + mx; r.fy = cy + my; r.fz = cz + mz;
+  return r;
+}
+__device__ __forceinline__ bool own16_box_test(const uint4 q, const Own16Ray& r, bool negx, bool negy, bool negz) {
+  const float lx = (float)(q.x & 0xffffu), hx = (float)(q.y >> 16), ly = (float)(q.x >> 16), hy = (float)(q.z & 0xffffu), lz = (float)(q.y & 0xffffu),
+              hz = (float)(q.z >> 16);
+  const float tN = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(negx ? hx : lx, r.sx, r.nx), __builtin_fmaf(negy ? hy : ly, r.sy, r.ny)),
+                                   __builtin_fmaf(negz ? hz : lz, r.sz, r.nz));
+  const float tF = __builtin_fminf(__builtin_fminf(__builtin_fmaf(negx ? lx : hx, r.sx, r.fx), __builtin_fmaf(negy ? ly : hy, r.sy, r.fy)),
+                                   __builtin_fmaf(negz ? lz : hz, r.sz, r.fz));
+  return tF >= __builtin_fmaxf(tN, __uint_as_float(1u));
+}
+
+// the reference's own tests of a leaf noted by the walk: its box (acc.cl:113-130, finite form) and its triangle (acc.cl:72-111)
+template <int PROGRAM, bool ANYHIT>
+__device__ __forceinline__ bool own_leaf_test(const SceneDev& sc, uint32_t node, const Ray& ray, float ix, float iy, float iz, Hit& pl,
+                                              const uint32_t* rank8, uint32_t octant) {
+  const float4* r = (const float4*)((const char*)sc.ownPairs + ((size_t)node << 6));
+  const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];   // A e1.x | e1.yz e2.xy | e2.z lo | hi prim
+  // (all four loads in ONE round trip: left alone, the compiler fetches the box, tests it and only then fetches the triangle --
+  // two dependent round trips in a step that the other lanes of the wave sit through)
+  asm volatile("" ::"v"(r0.x), "v"(r1.x), "v"(r2.x), "v"(r3.x));
+  if (!box_test_finite(r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, ray, ix, iy, iz)) return false;
+  const int prim = __float_as_int(r3.w);
+  if (intersect_triangle_data<PROGRAM>(r0, r1, make_float4(r2.x, 0.0f, 0.0f, 0.0f), ray, pl, sc.fastRcp != 0u, rank8, octant, prim)) {
+    pl.prim = prim;
+    pl.hitType = 1;
+    return true;
+  }
+  return false;
+}
+
 template <int PROGRAM, bool ANYHIT>
 __device__ inline void traverse_own_lane(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl) {
   const uint32_t octant = (ix < 0.0f ? 1u : 0u) | (iy < 0.0f ? 2u : 0u) | (iz < 0.0f ? 4u : 0u);
   const uint32_t* const rank8 = ANYHIT ? nullptr : sc.rank8;
-  const bool fast = sc.fastRcp != 0u;
+  const Own16Ray qr = own16_ray(sc, ray, ix, iy, iz);
   const uint32_t end = sc.nOwn;
   uint32_t cur = 0u;
-  int pend = -1;
+  int pend = -1;   // a leaf (node index) whose quantised box was hit in the previous step
   do {
-    const float4* n = (const float4*)((const char*)sc.ownNodes + (cur << 5));   // (32-bit byte offset: checked at set_scene)
-    const float4 a = n[0], b = n[1];   // a = min.x min.y min.z max.x ; b = max.y max.z offset|escape count|axis<<16
+    const uint4 q = *(const uint4*)((const char*)sc.own16 + ((size_t)cur << 4));
     if (pend >= 0) {
-      if (intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, fast, rank8, octant)) {
-        pl.prim = pend;
-        pl.hitType = 1;
-        if (ANYHIT) return;
-      }
+      if (own_leaf_test<PROGRAM, ANYHIT>(sc, (uint32_t)pend, ray, ix, iy, iz, pl, rank8, octant) && ANYHIT) return;
     }
-    const bool hit = box_test_finite(a.x, a.y, a.z, a.w, b.x, b.y, ray, ix, iy, iz);
-    const bool leaf = (__float_as_uint(b.w) & 0xffffu) != 0u;
-    const int off = __float_as_int(b.z);
-    pend = (hit && leaf && off != ign) ? off : -1;
-    cur = (leaf || hit) ? cur + 1u : (uint32_t)off;
+    const bool hit = own16_box_test(q, qr, ix < 0.0f, iy < 0.0f, iz < 0.0f);
+    const bool leaf = (int)q.w < 0;
+    pend = (hit && leaf && (int)(q.w & 0x7fffffffu) != ign) ? (int)cur : -1;
+    cur = (leaf || hit) ? cur + 1u : q.w;
   } while (cur < end);
-  if (pend >= 0) {
-    if (intersect_triangle<PROGRAM>(sc.tris, pend, ray, pl, fast, rank8, octant)) {
-      pl.prim = pend;
-      pl.hitType = 1;
-    }
-  }
+  if (pend >= 0) own_leaf_test<PROGRAM, ANYHIT>(sc, (uint32_t)pend, ray, ix, iy, iz, pl, rank8, octant);
 }
 
 // Compile-time configuration of one kernel instantiation.
@@ -600,13 +672,6 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
 // lane mask ("this lane hit every ancestor") beside each node index on a wave-uniform stack, so that every lane's tested nodes,
 // the order of its leaves and its work counters are exactly those of its own reference traversal -- and packet_walk (further
 // down; lt_walk_asm.hpp) for everything else: over the backend's own tree, order-free, mask-free.
-typedef float F4v __attribute__((ext_vector_type(4)));
-typedef float F8v __attribute__((ext_vector_type(8)));
-typedef const __attribute__((address_space(4))) F4v* ConstF4;   // constant address space: uniform loads become s_load
-typedef const __attribute__((address_space(4))) F8v* ConstF8;
-typedef float F16v __attribute__((ext_vector_type(16)));
-typedef const __attribute__((address_space(4))) F16v* ConstF16;
-__device__ __forceinline__ float4 ld_const(ConstF4 p) { const F4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 
 template <int PROGRAM, bool STATS>
 __device__ inline void traverse_packet(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, bool nxU, bool nyU, bool nzU,
@@ -746,13 +811,15 @@ __device__ __forceinline__ void packet_walk(const SceneDev& sc, const Ray& ray, 
   if constexpr (NEG >= 0 || ANYHIT) {
     const float eps = (PROGRAM == kBasic || PROGRAM == kCustom) ? 0.0000001f
                       : (PROGRAM == kBasicLighting) ? __uint_as_float(0x33d6bf95u) : __uint_as_float(0x38d1b718u);
+    // the wave's first LDS row (byte address), where the walk parks its stack register's lanes (LT_ASM_WALK)
+    const uint32_t ldsrow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) int*)ldsWave);
     if constexpr (ANYHIT) {
       const unsigned long long open = packet_anyhit_walk<NEG>((const void*)sc.ownPairs, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y,
-                                                              ray.d.z, ray.d.w, pl.t, ign, eps, sc.fastRcp, __builtin_amdgcn_ballot_w64(true));
+                                                              ray.d.z, ray.d.w, pl.t, ign, eps, sc.fastRcp, __builtin_amdgcn_ballot_w64(true), ldsrow);
       pl.hitType = ((open >> __lane_id()) & 1ull) != 0ull ? pl.hitType : 1;
     } else {
       packet_closest_walk<NEG>((const void*)sc.ownPairs, (const void*)sc.rank8, ray.o.x, ray.o.y, ray.o.z, ix, iy, iz, ray.d.x, ray.d.y,
-                               ray.d.z, ray.d.w, eps, sc.fastRcp, pl.t, pl.u, pl.v, pl.prim, pl.hitType);
+                               ray.d.z, ray.d.w, eps, sc.fastRcp, pl.t, pl.u, pl.v, pl.prim, pl.hitType, ldsrow);
     }
     return;
   }
@@ -819,8 +886,9 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
   if (__all(finite)) {
     // (not in the global-illumination programs: most of their shadow rays start at bounce hits and are incoherent, and the
     // extra walks cost their register-heavy kernels a third of their speed on small scenes)
-    bool asPacket = ANYHIT && !DEEP && PROGRAM != kGI && PROGRAM != kGI25 && sc.shadowPackets != 0u && sc.rank8 != nullptr &&
-                    __all(packet_ray_ok(ray, ix, iy, iz));
+    // (the walks over the own tree test interior boxes conservatively, which wants rays of ordinary magnitudes: packet_ray_ok)
+    const bool ownWalks = sc.rank8 != nullptr && __all(packet_ray_ok(ray, ix, iy, iz));
+    bool asPacket = ANYHIT && !DEEP && PROGRAM != kGI && PROGRAM != kGI25 && sc.shadowPackets != 0u && ownWalks;
     if (asPacket && sc.shadowPackets == 2u) {   // per wavefront: are these 64 rays one bundle?
       auto first = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
       const float rx = first(ray.o.x), ry = first(ray.o.y), rz = first(ray.o.z);
@@ -848,7 +916,7 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
       return;
     }
     if constexpr (!STATS && !LDSSCENE) {
-      if (sc.rank8 != nullptr) {   // (the scene has a tree of the backend's own: lt_hip_set_scene)
+      if (ownWalks) {   // (the scene has a tree of the backend's own: lt_hip_set_scene)
         traverse_own_lane<PROGRAM, ANYHIT>(sc, ray, ix, iy, iz, useIgnore ? ignore : -1, pl);
         return;
       }

@@ -21,7 +21,8 @@
 //     the mask of lanes that accept the hit;
 //   * no order, no lane masks: every popped node is tested by every lane still in the walk (a lane outside the node's parent
 //     cannot be inside the node), so a stack entry is ONE dword -- a node index, bit 31 set for a leaf -- and the stack is one
-//     VGPR whose 64 lanes are its 64 slots (v_writelane / v_readlane with the stack pointer in M0): no LDS, no latency.  Pushes
+//     VGPR whose 64 lanes are its 64 slots (v_writelane / v_readlane with the stack pointer in M0): no LDS, no latency (the
+//     register's 64 lanes are parked in the wave's LDS row around a walk that runs with lanes switched off: LT_ASM_WALK).  Pushes
 //     are branch-free: write the child at the top, then add "some lane hit it" (SCC of s_cmp_lg_u64) to the pointer.  Depth:
 //     at most two waiting entries per level plus four at the frontier, 2 * height + 2 <= 62 (the build caps the height at 30);
 //   * two interior nodes per iteration when the stack holds two: their records are fetched together, halving the number of
@@ -312,6 +313,18 @@ typedef unsigned long long lt_u64;
 #define LT_ASM_WALK(NF, LIVE, IGNORE, ACCEPT)                                                                                   \
   "s_mov_b64 " LT_R_EXEC ", exec\n"                                                                                             \
   "s_mov_b32 " LT_R_M0 ", m0\n"                                                                                                 \
+  /* v_writelane ignores EXEC: a stack slot is a LANE of the stack register, and where that lane is switched off (a pixel that  \
+     ended at a light, a pixel outside the image) the same physical register may hold a live value of that lane's own path --   \
+     the compiler allocates registers per thread.  So, unless every lane is on, all 64 lanes of the register are parked in the  \
+     wave's LDS row for the duration of the walk (ds_write_addtid: address = M0 + 4 * lane, no address register needed). */     \
+  "s_cmp_eq_u64 exec, -1\n"                                                                                                     \
+  "s_cbranch_scc1 .Lsaved%=\n"                                                                                                  \
+  "s_mov_b32 m0, %[ldsrow]\n"                                                                                                   \
+  "s_mov_b64 exec, -1\n"                                                                                                        \
+  "ds_write_addtid_b32 %[stk]\n"                                                                                                \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
+  "s_mov_b64 exec, " LT_R_EXEC "\n"                                                                                             \
+  ".Lsaved%=:\n"                                                                                                                \
   "s_mov_b32 m0, 0\n"                               /* the stack pointer lives in M0 */                                         \
   "s_mov_b32 " LT_R_CUR ", 0\n"                     /* the root: interior node 0 */                                             \
   "s_branch .Lnode%=\n"                                                                                                         \
@@ -368,6 +381,13 @@ typedef unsigned long long lt_u64;
   ".LleafEnd%=:\n"                                                                                                              \
   "s_branch .Lpop%=\n"                                                                                                          \
   ".Ldone%=:\n"                                                                                                                 \
+  "s_cmp_eq_u64 " LT_R_EXEC ", -1\n"                                                                                            \
+  "s_cbranch_scc1 .Lrestored%=\n"                                                                                               \
+  "s_mov_b32 m0, %[ldsrow]\n"                                                                                                   \
+  "s_mov_b64 exec, -1\n"                                                                                                        \
+  "ds_read_addtid_b32 %[stk]\n"                     /* every lane of the stack register as it was */                            \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
+  ".Lrestored%=:\n"                                                                                                             \
   "s_mov_b32 m0, " LT_R_M0 "\n"                                                                                                 \
   "s_mov_b64 exec, " LT_R_EXEC "\n"
 
@@ -390,7 +410,8 @@ __device__ __forceinline__ PacketRay packet_ray(float ox, float oy, float oz, fl
 // share; eps = the program's triangle epsilon as the float the reference's double compare amounts to (intersect_triangle_data).
 template <int NEG>
 __device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, float ox, float oy, float oz, float ix, float iy, float iz, float dx,
-                                                     float dy, float dz, float dw, float tmax, int ign, float eps, uint32_t fast, lt_u64 open) {
+                                                     float dy, float dz, float dw, float tmax, int ign, float eps, uint32_t fast, lt_u64 open,
+                                                     uint32_t ldsrow) {
   const PacketRay pr = packet_ray(ox, oy, oz, ix, iy, iz);
   int stk = 0;
   float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
@@ -400,7 +421,7 @@ __device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, float ox
                  [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9), [t10] "=&v"(t10)                        \
                : [pairs] "s"(pairs), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [px] "v"(pr.px),  \
                  [py] "v"(pr.py), [pz] "v"(pr.pz), [mg] "v"(pr.mg), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [dw] "v"(dw),                \
-                 [tmax] "v"(tmax), [ign] "v"(ign), [eps] "s"(eps), [fast] "s"(fast)                                                       \
+                 [tmax] "v"(tmax), [ign] "v"(ign), [eps] "s"(eps), [fast] "s"(fast), [ldsrow] "s"(ldsrow)                                 \
                : LT_ASM_CLOBBERS)
   if constexpr (NEG == 0) LT_ANYHIT_INSTANCE(LT_NF_0);
   else if constexpr (NEG == 1) LT_ANYHIT_INSTANCE(LT_NF_1);
@@ -419,7 +440,7 @@ __device__ __forceinline__ lt_u64 packet_anyhit_walk(const void* pairs, float ox
 template <int NEG>
 __device__ __forceinline__ void packet_closest_walk(const void* pairs, const void* ranks, float ox, float oy, float oz, float ix, float iy,
                                                     float iz, float dx, float dy, float dz, float dw, float eps, uint32_t fast, float& pt,
-                                                    float& pu, float& pv, int& pprim, int& phit) {
+                                                    float& pu, float& pv, int& pprim, int& phit, uint32_t ldsrow) {
   const PacketRay pr = packet_ray(ox, oy, oz, ix, iy, iz);
   int stk = 0;
   float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
@@ -430,7 +451,7 @@ __device__ __forceinline__ void packet_closest_walk(const void* pairs, const voi
                  [t8] "=&v"(t8), [t9] "=&v"(t9), [t10] "=&v"(t10)                                                                        \
                : [pairs] "s"(pairs), [ranks] "s"(ranks), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy),            \
                  [iz] "v"(iz), [px] "v"(pr.px), [py] "v"(pr.py), [pz] "v"(pr.pz), [mg] "v"(pr.mg), [dx] "v"(dx), [dy] "v"(dy),            \
-                 [dz] "v"(dz), [dw] "v"(dw), [eps] "s"(eps), [fast] "s"(fast)                                                             \
+                 [dz] "v"(dz), [dw] "v"(dw), [eps] "s"(eps), [fast] "s"(fast), [ldsrow] "s"(ldsrow)                                       \
                : LT_ASM_CLOBBERS)
   if constexpr (NEG == 0) LT_CLOSEST_INSTANCE(LT_NF_0, "0");
   else if constexpr (NEG == 1) LT_CLOSEST_INSTANCE(LT_NF_1, "4");

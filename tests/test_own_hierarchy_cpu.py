@@ -195,3 +195,105 @@ def test_conservative_test_accepts_whenever_the_reference_does(scale):
     ref, con = reference_test(lo, hi, o, inv), conservative_test(lo, hi, o, inv)
     assert not (ok & ref & ~con).any()
     assert (ok & con & ~ref).sum() <= 1e-3 * ok.sum() + 5
+
+
+# ---- the per-lane walks' 16-byte quantised nodes (lt_own16.hpp, traverse_own_lane) --------------------------------------------
+def chain_tree(lo, hi):
+    """A caller's tree over n leaf boxes in the reference's layout: a right-leaning chain (interior node 2k: left child = leaf
+    2k + 1, right child = the rest), every interior box the union of what is below it.  Leaf k refers to primitive k."""
+    n = len(lo)
+    nodes = np.zeros(2 * n - 1, dtype=sc.NODE_DTYPE)
+    sufmin = np.minimum.accumulate(lo[::-1], axis=0)[::-1]
+    sufmax = np.maximum.accumulate(hi[::-1], axis=0)[::-1]
+    for k in range(n - 1):
+        i = 2 * k
+        nodes["boundsMin"][i], nodes["boundsMax"][i] = sufmin[k], sufmax[k]
+        nodes["offset"][i] = i + 2
+        nodes["boundsMin"][i + 1], nodes["boundsMax"][i + 1] = lo[k], hi[k]
+        nodes["offset"][i + 1], nodes["primitiveCount"][i + 1] = k, 1
+    nodes["boundsMin"][-1], nodes["boundsMax"][-1] = lo[-1], hi[-1]
+    nodes["offset"][-1], nodes["primitiveCount"][-1] = n - 1, 1
+    return nodes
+
+
+def random_boxes(rng, n, scale, centre):
+    c = centre + rng.uniform(-scale, scale, (n, 3))
+    half = np.abs(rng.normal(0, scale * 0.02, (n, 3))) * rng.choice([0.0, 1e-4, 1.0], (n, 3))     # flat and sliver boxes too
+    return (c - half).astype(f32), (c + half).astype(f32)
+
+
+@pytest.mark.parametrize("scale,centre", [(1.0, 0.0), (1e-3, 0.0), (50.0, 10.0), (1.0, 3000.0), (1e6, 0.0)])
+def test_quantised_nodes_enclose_their_boxes_and_keep_the_links(scale, centre):
+    rng = np.random.default_rng(11)
+    lo, hi = random_boxes(rng, 3000, scale, centre)
+    h, own, _ = C.own_hierarchy(chain_tree(lo, hi), len(lo), 2)
+    assert h >= 0
+    O, S, rec = C.own_quantised(own)
+    q = rec["q"].astype(np.float64)
+    L = O.astype(np.float64) + q[:, :3] * S.astype(np.float64)
+    H = O.astype(np.float64) + q[:, 3:] * S.astype(np.float64)
+    blo, bhi = own["boundsMin"].astype(np.float64), own["boundsMax"].astype(np.float64)
+    u = 2.0 ** -24
+    assert np.all(L <= blo - 8 * u * np.abs(blo)) and np.all(H >= bhi + 8 * u * np.abs(bhi))
+    # ... and tightly: at most two grid steps and 2^-20 of the bound away
+    assert np.all(blo - L <= 2 * S + 2.0 ** -20 * np.abs(blo) + 1e-44) and np.all(H - bhi <= 2 * S + 2.0 ** -20 * np.abs(bhi) + 1e-44)
+    leaf = own["primitiveCount"] != 0
+    assert np.array_equal(rec["link"][leaf], own["offset"][leaf].astype(np.uint32) | np.uint32(0x80000000))
+    # an interior node's link is its escape: the node after its subtree in pre-order
+    n = len(own)
+    esc = np.zeros(n, dtype=np.int64)
+    for i in range(n - 1, -1, -1):
+        esc[i] = i + 1 if leaf[i] else esc[int(own["offset"][i])]
+    assert np.array_equal(rec["link"][~leaf].astype(np.int64), esc[~leaf])
+
+
+def own16_test(O, S, q, o, inv):
+    """own16_ray + own16_box_test (lt_device.hpp) in float32 arithmetic: per-axis margins folded into the two constants, the
+    near / far bound picked by the direction's sign."""
+    p = (o * inv).astype(f32)
+    sI = (S[None, :] * inv).astype(f32)
+    Ob = np.broadcast_to(O, inv.shape).astype(f32)
+    c = fma32(Ob, inv, -p)
+    k = (np.abs(((f32(65535.0) * S[None, :]).astype(f32) * inv).astype(f32)) + np.abs((Ob * inv).astype(f32))).astype(f32)
+    k = (k + np.abs(p)).astype(f32)
+    m = ((k * f32(2.0 ** -21)).astype(f32) + f32(2.0 ** -140)).astype(f32)
+    cN, cF = (c - m).astype(f32), (c + m).astype(f32)
+    neg = inv < 0
+    ql, qh = q[:, :3].astype(f32), q[:, 3:].astype(f32)
+    t_enter = fma32(np.where(neg, qh, ql), sI, cN).max(axis=-1)
+    t_exit = fma32(np.where(neg, ql, qh), sI, cF).min(axis=-1)
+    return t_exit >= np.maximum(t_enter, np.float32(1e-45))
+
+
+@pytest.mark.parametrize("scale,centre", [(1.0, 0.0), (1e-3, 0.0), (50.0, 10.0), (1.0, 3000.0), (1e6, 0.0)])
+def test_quantised_test_accepts_whenever_the_reference_accepts_the_true_box(scale, centre):
+    rng = np.random.default_rng(5)
+    lo, hi = random_boxes(rng, 4000, scale, centre)
+    _, own, _ = C.own_hierarchy(chain_tree(lo, hi), len(lo), 2)
+    O, S, rec = C.own_quantised(own)
+    reps = 60
+    idx = np.tile(np.arange(len(own)), reps)
+    n = len(idx)
+    blo, bhi, q = own["boundsMin"][idx], own["boundsMax"][idx], rec["q"][idx]
+    o = (centre + rng.uniform(-scale, scale, (n, 3)) * rng.choice([1.0, 3.0, 100.0], (n, 1))).astype(f32)
+    w = rng.choice([0.0, 1.0, 0.5], (n, 3))                       # aim at the box's faces, edges and corners, a few ulps off
+    target = (blo * (1 - w) + bhi * w).astype(f32)
+    d = (target - o).astype(f32)
+    d = (d * (1 + rng.integers(-3, 4, (n, 3)) * 2.0 ** -23)).astype(f32)
+    with np.errstate(divide="ignore", over="ignore", invalid="ignore"):
+        inv = (f32(1.0) / d).astype(f32)
+        ok = np.isfinite(inv).all(axis=-1) & (np.abs(inv) < 2.0 ** 60).all(axis=-1)
+        ref = reference_test(blo, bhi, o, inv)
+        con = own16_test(O, S, q, o, inv)
+    assert ok.sum() > n // 2 and ref[ok].sum() > n // 20
+    missed = ok & ref & ~con
+    assert not missed.any(), "%d rays pass the reference's slab test of a box and fail the test of its quantised node" % int(missed.sum())
+    # not vacuous: random rays that miss the true box by more than a few grid steps miss the quantised node too
+    d = rng.normal(0, 1, (n, 3)).astype(f32)
+    inv = (f32(1.0) / d).astype(f32)
+    ok = (np.abs(inv) < 2.0 ** 60).all(axis=-1)
+    ref, con = reference_test(blo, bhi, o, inv), own16_test(O, S, q, o, inv)
+    assert not (ok & ref & ~con).any()
+    # (a scene far from the origin relative to its size pays for it: the boxes' outward push and the test's margin are relative
+    # to the coordinates' magnitude, 2^-21 of 3000 against boxes of 0.02 -- looser tests, never wrong ones)
+    assert (ok & con & ~ref).sum() <= (1.0 if centre > 100.0 else 0.02) * max(1, (ok & ref).sum()) + 5
