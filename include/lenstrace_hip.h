@@ -183,7 +183,8 @@ int lt_hip_resolve_program(lt_hip_context* ctx, const char* kernel_file_path, in
  * Derived at upload: the traversal-side triangle array (48-byte stride: A, B-A, C-A) and -- when every node's box encloses
  * its children's, which the reference's own builder guarantees -- the backend's OWN hierarchy over the caller's leaves
  * (binned surface-area heuristic, built on the host: ~0.1-0.4 s for a million triangles), the 64-byte records of its packet
- * walks, the 16-byte quantised nodes of its per-lane walks and the reference's leaf order per direction-sign octant.  The caller's LinearBVHNode array stays resident and is
+ * walks, the 4-wide groups of quantised boxes and the leaf records of its per-lane walks and the reference's leaf order per
+ * direction-sign octant.  The caller's LinearBVHNode array stays resident and is
  * what the counting kernels (LT_RENDER_FLAG_STATS / _PIXEL_COUNTERS), rays with a non-finite component and scenes whose
  * boxes do not nest walk, in the reference's order.  Pixels do not depend on which hierarchy a ray walked
  * (lens_trace_amd/csrc/lt_retree.hpp).  LT_RETREE=0 keeps the caller's splits. */
@@ -219,13 +220,16 @@ int lt_hip_synchronize(lt_hip_context* ctx, void* hip_stream);
 int lt_hip_own_hierarchy(const void* nodes, uint64_t node_bytes, int height_slack, void* out_nodes, uint64_t out_bytes,
                          uint32_t* rank8, uint32_t n_prims);
 
-/* Host only, no context, no GPU: what lt_hip_set_scene makes of that hierarchy for its per-lane walks -- one 16-byte record per
- * node (own_nodes: the array lt_hip_own_hierarchy wrote): the node's box on a 16-bit grid over the scene's bounds, rounded
- * outwards, as six uint16 (lo.x lo.y lo.z hi.x hi.y hi.z), then one uint32: an interior node's escape index (the node that
- * follows its subtree in pre-order), or 0x80000000 | primitive offset for a leaf.  origin_step receives the grid: origin xyz,
- * step xyz (bound = origin + q * step).  Returns 0, or -1 (bad arguments / a bound off the grid).  The same arithmetic runs on
- * the GPU at upload (lens_trace_amd/csrc/lt_own16.hpp). */
-int lt_hip_own_quantised(const void* own_nodes, uint64_t node_bytes, float* origin_step, void* out_records, uint64_t out_bytes);
+/* Host only, no context, no GPU: what lt_hip_set_scene makes of that hierarchy (own_nodes: the array lt_hip_own_hierarchy wrote)
+ * for its per-lane walks -- the tree collapsed into 4-wide groups, numbered depth first.  out_slots receives four 16-byte child
+ * slots per group: the child's box on a 16-bit grid over the scene's bounds, rounded outwards, as six uint16 (lo.x lo.y lo.z hi.x
+ * hi.y hi.z), then one uint32 link: the child's own group, or 0x80000000 | (groups + primitive offset) for a leaf (the index of its
+ * 64-byte record behind the groups); an empty slot holds lo = 65535, hi = 0 and the link 0x80000000 | (groups + n_prims).
+ * origin_step receives the grid: origin xyz, step xyz (bound = origin + q * step); *out_groups the number of groups (at most
+ * leaves - 1: size out_slots for that).  Returns the height of the group tree, or -1 (bad arguments, two leaves on one
+ * primitive, a bound off the grid).  The same arithmetic runs on the GPU at upload (lens_trace_amd/csrc/lt_own16.hpp). */
+int lt_hip_own_wide(const void* own_nodes, uint64_t node_bytes, uint32_t n_prims, float* origin_step, void* out_slots, uint64_t out_bytes,
+                    uint32_t* out_groups);
 
 /* Statistics of the most recent render call on ctx (waits for it to finish). */
 int lt_hip_get_stats(lt_hip_context* ctx, lt_hip_stats* out);

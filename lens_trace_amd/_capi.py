@@ -24,7 +24,7 @@ RENDER_FLAG_STRICT_MATH = 16
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",
            "lt_hip_resolve_program",
            "lt_hip_set_scene", "lt_hip_output_floats", "lt_hip_render", "lt_hip_render_device", "lt_hip_untile",
-           "lt_hip_synchronize", "lt_hip_get_stats", "lt_hip_own_hierarchy", "lt_hip_own_quantised"]
+           "lt_hip_synchronize", "lt_hip_get_stats", "lt_hip_own_hierarchy", "lt_hip_own_wide"]
 
 
 class RenderDesc(ctypes.Structure):
@@ -128,18 +128,20 @@ def own_hierarchy(nodes, n_prims=0, height_slack=2, want_ranks=False):
     return h, out, ranks
 
 
-OWN16_DTYPE = [("q", "<u2", (6,)), ("link", "<u4")]   # lo.x lo.y lo.z hi.x hi.y hi.z on the grid; escape index or 0x80000000 | primitive
+OWN16_DTYPE = [("q", "<u2", (6,)), ("link", "<u4")]   # a child slot: lo.x lo.y lo.z hi.x hi.y hi.z on the grid; the child's group or 0x80000000 | leaf record
 
 
-def own_quantised(own_nodes):
-    """lt_hip_own_quantised (host only): (origin[3], step[3], records as an OWN16_DTYPE array) of an own hierarchy."""
+def own_wide(own_nodes, n_prims):
+    """lt_hip_own_wide (host only): (height of the group tree, origin[3], step[3], slots as an OWN16_DTYPE array of shape (groups, 4))."""
     import numpy as np
     own_nodes = np.ascontiguousarray(own_nodes)
     frame = np.zeros(6, dtype=np.float32)
-    out = np.zeros(len(own_nodes), dtype=OWN16_DTYPE)
+    out = np.zeros((max(1, len(own_nodes) // 2), 4), dtype=OWN16_DTYPE)
     assert out.dtype.itemsize == 16
-    rc = load().lt_hip_own_quantised(own_nodes.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(own_nodes.nbytes),
-                                     frame.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(out.nbytes))
-    if rc:
-        raise LensTraceError(LT_ERR_BAD_SCENE, "lt_hip_own_quantised failed")
-    return frame[:3].copy(), frame[3:].copy(), out
+    groups = ctypes.c_uint32(0)
+    h = load().lt_hip_own_wide(own_nodes.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(own_nodes.nbytes), ctypes.c_uint32(n_prims),
+                               frame.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(out.nbytes),
+                               ctypes.byref(groups))
+    if h < 0:
+        raise LensTraceError(LT_ERR_BAD_SCENE, "lt_hip_own_wide failed")
+    return h, frame[:3].copy(), frame[3:].copy(), out[:groups.value].copy()

@@ -60,21 +60,53 @@ __global__ void lt_own_pair_kernel(const float4* __restrict__ nodes, const float
   }
 }
 
-// The per-lane walks' 16-byte nodes (SceneDev::own16, traverse_own_lane), from the own tree in its threaded form (an interior
-// node's `off` = its escape index): the node's box on a 16-bit grid over the scene's bounds, rounded outwards -- q such that, in
-// real arithmetic, O + ql S <= lo - 8u|lo| and O + qh S >= hi + 8u|hi| (lt_own16.hpp: `outwards` gives 9u; the sums are formed
-// in double: exact, or within 2^-53 of the scene's extent, far inside the spare factor of two of the walk's margin) -- and the
-// link: the escape index, or 0x80000000 | primitive offset for a leaf.  *bad is set when a bound falls off the grid (the host
-// sizes the grid from the root's box with room to spare; the scene then simply gets no hierarchy of the backend's own).
+// The per-lane walks' records (SceneDev::wide, traverse_own_lane), 64 bytes each, one array:
+//   [0, groups)                          the 4-wide groups of lt_retree::collapse_wide: four 16-byte child slots -- the child's box
+//                                        on a 16-bit grid over the scene's bounds, rounded outwards (lt_own16.hpp: in real
+//                                        arithmetic O + ql S <= lo - 8u|lo| and O + qh S >= hi + 8u|hi|), and its link;
+//   [groups, groups + n_prims]           leaf records by primitive offset: the triangle re-tiled (A, B - A, C - A: lt_retile_kernel's
+//                                        arithmetic), the leaf's own box bit for bit, the offset -- what the reference's leaf test
+//                                        needs -- and one more behind them whose box is NaN (the target of empty slots).
+// *bad is set when a bound falls off the grid (the host sizes the grid from the root's box with room to spare; the scene then
+// simply gets no hierarchy of the backend's own).
 struct Own16Frame { float O[3], S[3]; };
-__global__ void lt_own16_kernel(const float4* __restrict__ nodes, uint4* __restrict__ out, uint32_t n, Own16Frame fr, uint32_t* __restrict__ bad) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__global__ void lt_wide_kernel(const float4* __restrict__ nodes, const uint32_t* __restrict__ children, const uint32_t* __restrict__ groupOf,
+                               uint4* __restrict__ wide, uint32_t groups, uint32_t n_prims, Own16Frame fr, uint32_t* __restrict__ bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // slot
+  if (i >= 4u * groups) return;
+  const uint32_t child = children[i];
+  lt_own16::Rec r = lt_own16::empty_slot(groups, n_prims);
+  if (child != 0xffffffffu) {
+    const float4 a = nodes[2 * (size_t)child], b = nodes[2 * (size_t)child + 1];
+    const float lo[3] = {a.x, a.y, a.z}, hi[3] = {a.w, b.x, b.y};
+    const bool leaf = (__float_as_uint(b.w) & 0xffffu) != 0u;
+    const uint32_t link = leaf ? (0x80000000u | (groups + __float_as_uint(b.z))) : groupOf[child];
+    if (!lt_own16::slot_record(lo, hi, link, fr.O, fr.S, r)) atomicOr(bad, 1u);
+  }
+  wide[i] = make_uint4(r.x, r.y, r.z, r.w);
+}
+__global__ void lt_wide_leaf_kernel(const float4* __restrict__ nodes, const float* __restrict__ prims, float4* __restrict__ wide, uint32_t n,
+                                    uint32_t groups, uint32_t n_prims) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // node of the own tree; thread n writes the record behind the last primitive's
+  if (i > n) return;
+  if (i == n) {
+    const float q = __uint_as_float(0x7fc00000u);
+    float4* r = wide + 4 * ((size_t)groups + n_prims);
+    r[0] = r[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    r[2] = make_float4(0.0f, q, q, q);
+    r[3] = make_float4(q, q, q, __uint_as_float(n_prims));
+    return;
+  }
   const float4 a = nodes[2 * (size_t)i], b = nodes[2 * (size_t)i + 1];
-  const float lo[3] = {a.x, a.y, a.z}, hi[3] = {a.w, b.x, b.y};
-  lt_own16::Rec r;
-  if (!lt_own16::node_record(lo, hi, __float_as_uint(b.z), (__float_as_uint(b.w) & 0xffffu) != 0u, fr.O, fr.S, r)) atomicOr(bad, 1u);
-  out[i] = make_uint4(r.x, r.y, r.z, r.w);
+  if ((__float_as_uint(b.w) & 0xffffu) == 0u) return;
+  const uint32_t prim = __float_as_uint(b.z);
+  const float* p = prims + 19 * (size_t)prim;
+  const float ax = p[0], ay = p[1], az = p[2];
+  float4* r = wide + 4 * ((size_t)groups + prim);
+  r[0] = make_float4(ax, ay, az, p[3] - ax);
+  r[1] = make_float4(p[4] - ay, p[5] - az, p[6] - ax, p[7] - ay);
+  r[2] = make_float4(p[8] - az, a.x, a.y, a.z);
+  r[3] = make_float4(a.w, b.x, b.y, b.z);
 }
 
 // Gathered per-rank tile stacks -> row-major image (root side of the one gather per frame).
@@ -129,8 +161,9 @@ struct lt_hip_context {
   void *d_nodes = nullptr, *d_tris = nullptr, *d_prims = nullptr, *d_mats = nullptr, *d_lights = nullptr;
   void *d_nodes2 = nullptr, *d_pairs2 = nullptr;   // the backend's own tree over the scene's leaves (lt_retree.hpp), or null
   void* d_rank8 = nullptr;                         // with it: the reference's leaf order per direction-sign octant (SceneDev::rank8)
-  void* d_own16 = nullptr;                         // ... and the per-lane walks' 16-byte nodes (SceneDev::own16) on the grid q16_origin + q * q16_step
-  float q16_origin[3] = {0, 0, 0}, q16_step[3] = {1, 1, 1};
+  void* d_wide = nullptr;                          // ... and the per-lane walks' 4-wide groups and leaf records (SceneDev::wide; 64 bytes in front: the grid)
+  uint32_t n_wide = 0;                             // groups
+  int wide_height = 0;
   int height2 = 0;                                 // its height
   uint32_t n_nodes2 = 0;
   float retree_ms = 0.0f;                          // host time of its build
@@ -162,7 +195,7 @@ struct lt_hip_context {
   bool pending = false, pending_stats = false;
   lt_hip_stats last{};
   // wavefront GI pipeline: path queues, per-pixel direct / indirect / blend, control block (queue lengths, work counters)
-  void* d_gi[11] = {nullptr};
+  void* d_gi[17] = {nullptr};
   uint64_t gi_pixels = 0;
   uint32_t* d_giCtl = nullptr;
   // user programs (hipRTC), cached by path like the reference's programMap
@@ -221,7 +254,7 @@ extern "C" int lt_hip_create(int device_index, lt_hip_context** out_ctx) {
 }
 
 static void free_scene(lt_hip_context* ctx) {
-  for (void** p : {&ctx->d_nodes, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights, &ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_rank8, &ctx->d_own16}) {
+  for (void** p : {&ctx->d_nodes, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights, &ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_rank8, &ctx->d_wide}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -467,21 +500,32 @@ extern "C" int lt_hip_own_hierarchy(const void* nodes, uint64_t node_bytes, int 
   return h;
 }
 
-extern "C" int lt_hip_own_quantised(const void* own_nodes, uint64_t node_bytes, float* origin_step, void* out_records, uint64_t out_bytes) {
-  if (!own_nodes || !origin_step || !out_records || node_bytes == 0 || node_bytes % 32 || node_bytes > 0xffffffffull) return -1;
+extern "C" int lt_hip_own_wide(const void* own_nodes, uint64_t node_bytes, uint32_t n_prims, float* origin_step, void* out_slots, uint64_t out_bytes,
+                               uint32_t* out_groups) {
+  if (!own_nodes || !origin_step || !out_slots || !out_groups || node_bytes == 0 || node_bytes % 32 || node_bytes > 0xffffffffull) return -1;
   const uint32_t n = (uint32_t)(node_bytes / 32);
-  if (out_bytes < (uint64_t)n * 16) return -1;
   const lt_retree::Node* src = (const lt_retree::Node*)own_nodes;
+  if (n < 3 || src[0].cnt != 0) return -1;
   for (uint32_t i = 0; i < n; i++)   // (a pre-order tree: children behind their parent, in range)
     if (src[i].cnt == 0 && (i + 1 >= n || src[i].off <= (int32_t)i + 1 || (uint32_t)src[i].off >= n)) return -1;
-  std::vector<lt_retree::Node> own(src, src + n);
-  lt_retree::thread(own);
+  const std::vector<lt_retree::Node> own(src, src + n);
+  std::vector<uint32_t> children, groupOf;
+  const int height = lt_retree::collapse_wide(own, n_prims, children, groupOf);
+  if (height < 0) return -1;
+  const uint32_t groups = (uint32_t)(children.size() / 4);
+  if (out_bytes < (uint64_t)groups * 64) return -1;
   for (int a = 0; a < 3; a++) lt_own16::frame(own[0].lo[a], own[0].hi[a], origin_step[a], origin_step[3 + a]);
-  lt_own16::Rec* out = (lt_own16::Rec*)out_records;
+  lt_own16::Rec* out = (lt_own16::Rec*)out_slots;
   bool ok = true;
-  for (uint32_t i = 0; i < n; i++)
-    ok = lt_own16::node_record(own[i].lo, own[i].hi, (uint32_t)own[i].off, own[i].cnt != 0, origin_step, origin_step + 3, out[i]) && ok;
-  return ok ? 0 : -1;
+  for (size_t i = 0; i < children.size(); i++) {
+    const uint32_t c = children[i];
+    out[i] = lt_own16::empty_slot(groups, n_prims);
+    if (c == 0xffffffffu) continue;
+    const uint32_t link = own[c].cnt != 0 ? (0x80000000u | (groups + (uint32_t)own[c].off)) : groupOf[c];
+    ok = lt_own16::slot_record(own[c].lo, own[c].hi, link, origin_step, origin_step + 3, out[i]) && ok;
+  }
+  *out_groups = groups;
+  return ok ? height : -1;
 }
 
 extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims,
@@ -548,32 +592,48 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
       hipLaunchKernelGGL(lt_own_pair_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2,
                          (const float*)ctx->d_prims, (float4*)ctx->d_pairs2, n2);
       LT_HIP_CHECK(ctx, hipGetLastError());
-      LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-      lt_retree::thread(own);   // (the pair records are made: now the form the stackless per-lane walks want, escape links)
-      LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_nodes2, own.data(), (size_t)n2 * 32, hipMemcpyHostToDevice));
-      // ... which read it as 16-byte quantised nodes (lt_own16.hpp); the 32-byte form is not kept
-      Own16Frame fr;
-      for (int a = 0; a < 3; a++) lt_own16::frame(own[0].lo[a], own[0].hi[a], fr.O[a], fr.S[a]);
-      LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_own16, (size_t)n2 * 16 + 32));   // (32 bytes in front: the grid, read by the walks themselves)
-      {
-        const float head[8] = {fr.O[0], fr.O[1], fr.O[2], 0.0f, fr.S[0], fr.S[1], fr.S[2], 0.0f};
-        LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_own16, head, sizeof(head), hipMemcpyHostToDevice));
+      // ... and the per-lane walks' 4-wide groups and leaf records, made from the same upload of the tree; the 32-byte form is not kept
+      std::vector<uint32_t> children, groupOf;
+      const int hw = lt_retree::collapse_wide(own, n_prims, children, groupOf);
+      const uint32_t groups = (uint32_t)(children.size() / 4);
+      // (the walk's stack: at most three waiting entries per level of groups and the four of the last one)
+      bool ownOk = hw >= 0 && 3 * hw + 4 <= kOwnRows + kOwnDeep && (uint64_t)groups + n_prims + 1 < 0x7fffffffull;
+      if (ownOk) {
+        Own16Frame fr;
+        for (int a = 0; a < 3; a++) lt_own16::frame(own[0].lo[a], own[0].hi[a], fr.O[a], fr.S[a]);
+        const size_t records = (size_t)groups + n_prims + 1;
+        void *d_children = nullptr, *d_groupOf = nullptr;
+        LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_wide, records * 64 + 64));   // (64 bytes in front: the grid, read by the walks themselves)
+        LT_HIP_CHECK(ctx, hipMalloc(&d_children, children.size() * 4));
+        LT_HIP_CHECK(ctx, hipMalloc(&d_groupOf, groupOf.size() * 4));
+        const float head[16] = {0, 0, 0, 0, 0, 0, 0, 0, fr.O[0], fr.O[1], fr.O[2], 0.0f, fr.S[0], fr.S[1], fr.S[2], 0.0f};
+        LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_wide, head, sizeof(head), hipMemcpyHostToDevice));
+        LT_HIP_CHECK(ctx, hipMemcpy(d_children, children.data(), children.size() * 4, hipMemcpyHostToDevice));
+        LT_HIP_CHECK(ctx, hipMemcpy(d_groupOf, groupOf.data(), groupOf.size() * 4, hipMemcpyHostToDevice));
+        LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long), ctx->stream));
+        uint4* wide = (uint4*)ctx->d_wide + 4;
+        hipLaunchKernelGGL(lt_wide_kernel, dim3((4 * groups + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2,
+                           (const uint32_t*)d_children, (const uint32_t*)d_groupOf, wide, groups, n_prims, fr, (uint32_t*)ctx->d_stats);
+        LT_HIP_CHECK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(lt_wide_leaf_kernel, dim3((n2 + 1 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2,
+                           (const float*)ctx->d_prims, (float4*)wide, n2, groups, n_prims);
+        LT_HIP_CHECK(ctx, hipGetLastError());
+        uint32_t bad = 0;
+        LT_HIP_CHECK(ctx, hipMemcpyAsync(&bad, ctx->d_stats, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+        LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_children);
+        (void)hipFree(d_groupOf);
+        ownOk = bad == 0;   // (a bound off the grid cannot happen for a grid sized from the root's box)
       }
-      LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long), ctx->stream));
-      hipLaunchKernelGGL(lt_own16_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2, (uint4*)ctx->d_own16 + 2, n2, fr,
-                         (uint32_t*)ctx->d_stats);
-      LT_HIP_CHECK(ctx, hipGetLastError());
-      uint32_t bad = 0;
-      LT_HIP_CHECK(ctx, hipMemcpyAsync(&bad, ctx->d_stats, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
-      LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
       LT_HIP_CHECK(ctx, hipFree(ctx->d_nodes2));
       ctx->d_nodes2 = nullptr;
-      if (bad) {   // (cannot happen for a grid sized from the root's box; the scene then walks the caller's tree)
-        for (void** p : {&ctx->d_pairs2, &ctx->d_own16}) { (void)hipFree(*p); *p = nullptr; }
+      if (!ownOk) {   // the scene then walks the caller's tree
+        for (void** p : {&ctx->d_pairs2, &ctx->d_wide}) { if (*p) (void)hipFree(*p); *p = nullptr; }
       } else {
-        for (int a = 0; a < 3; a++) { ctx->q16_origin[a] = fr.O[a]; ctx->q16_step[a] = fr.S[a]; }
         ctx->n_nodes2 = n2;
         ctx->height2 = h2;
+        ctx->n_wide = groups;
+        ctx->wide_height = hw;
         std::vector<uint32_t> rank8;
         lt_retree::reference_order(nodes, n_prims, rank8);
         LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_rank8, rank8.size() * sizeof(uint32_t)));
@@ -650,15 +710,16 @@ static void launch_program(const LaunchConfig& k, dim3 grid, uint32_t lds, hipSt
 #undef LT_LAUNCH
 }
 
-// 8 per-XCD square queues, queue lengths, bounce work counters: every counter in a cache line of its own
-constexpr uint32_t kGiCtlWords = (8 + 2 * (kMaxStack + 2)) * kQueueStride;
+// 8 per-XCD square queues, queue lengths, bounce work counters, trace work counters (extension rays, shadow rays), hit-list lengths:
+// every counter in a cache line of its own
+constexpr uint32_t kGiCtlWords = (8 + 19 * (kMaxStack + 2)) * kQueueStride;   // (the trace launches' counters come in eights: one per eighth of their queue)
 
 static int ensure_gi_buffers(lt_hip_context* ctx, uint64_t pixels) {
   if (!ctx->d_giCtl) LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_giCtl, kGiCtlWords * sizeof(uint32_t)));
   if (ctx->gi_pixels >= pixels) return LT_OK;
   for (void*& b : ctx->d_gi) { if (b) LT_HIP_CHECK(ctx, hipFree(b)); b = nullptr; }
   ctx->gi_pixels = 0;
-  for (int i = 0; i < 11; i++) LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_gi[i], pixels * 16));
+  for (int i = 0; i < 17; i++) LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_gi[i], pixels * 16));
   ctx->gi_pixels = pixels;
   return LT_OK;
 }
@@ -697,16 +758,56 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
     const int timed = ctx->shadow_mode[LT_PROGRAM_ACCUMULATOR];
     scPrimary.shadowPackets = spe ? (uint32_t)std::max(0, std::min(2, atoi(spe))) : (timed < 0 ? 1u : (uint32_t)timed);
   }
-  hipLaunchKernelGGL((lt_gi_primary_kernel<CFG>), dim3(gridA), dim3(kBlock), lds, s, scPrimary, fp, gp, queues);
-  LT_HIP_CHECK(ctx, hipGetLastError());
-  launches++;
   // A scene of a few hundred triangles rides in LDS for the bounce stages' per-lane walks (Config::kLdsScene): workgroups of
   // eight waves share one copy.  LT_GI_LDS_SCENE=0 turns it off (A/B measurements).
   const uint64_t sceneLdsBytes = (uint64_t)ctx->n_nodes * 32 + (uint64_t)ctx->n_prims * 48;
   const char* le = getenv("LT_GI_LDS_SCENE");
   const bool ldsScene = ctx->bvh_height <= kLdsStack && sceneLdsBytes <= 16384 && !(le && atoi(le) == 0);   // (its walks keep the LDS stack)
+  // With a tree of the backend's own to walk, a bounce stage is five launches instead of one (lt_kernel.hpp): its extension rays
+  // through lt_trace_kernel, whose lanes take a new ray when theirs is done; the paths sorted into light hits, misses and
+  // surface hits; the surface hits' light samples; their shadow rays through lt_trace_kernel; the survivors' next rays.
+  // LT_GI_TRACE=0: the one-kernel stage (A/B measurements).
+  const char* te = getenv("LT_GI_TRACE");
+  const bool pretrace = !ldsScene && ctx->d_rank8 != nullptr && !(te && atoi(te) == 0);
+  gp.hitCount = ctx->d_giCtl + (8 + 2 * (kMaxStack + 2)) * kQueueStride;
+  gp.directQueue = pretrace ? 1u : 0u;
+  hipLaunchKernelGGL((lt_gi_primary_kernel<CFG>), dim3(gridA), dim3(kBlock), lds, s, scPrimary, fp, gp, queues);
+  LT_HIP_CHECK(ctx, hipGetLastError());
+  launches++;
   gp.ldsRows = ctx->lds_ref_bytes / (kBlock * sizeof(int));   // (read by the multi-wave workgroups of the LDS-scene launches only)
+  uint32_t* traceWork = ctx->d_giCtl + (8 + 3 * (kMaxStack + 2)) * kQueueStride;    // 8 per stage
+  uint32_t* shadowWork = ctx->d_giCtl + (8 + 11 * (kMaxStack + 2)) * kQueueStride;  // 8 per stage
+  gp.hitList = (uint32_t*)ctx->d_gi[12];
+  gp.so = (float4*)ctx->d_gi[13]; gp.sd = (float4*)ctx->d_gi[14]; gp.sm = (uint4*)ctx->d_gi[15]; gp.sn = (float4*)ctx->d_gi[16];
+  const char* re = getenv("LT_TRACE_REFILL");
+  const uint32_t refill = re ? (uint32_t)std::max(1, std::min(64, atoi(re))) : 24u;
+  const uint32_t traceLds = (uint32_t)((kTraceRows + kTraceStage) * kBlock * sizeof(int));
+  const dim3 streamGrid((uint32_t)ctx->cu_count * 8u), streamBlock(256);
   for (int d = 0; d < fp.giMaxDepth; d++) {
+    gp.hits = nullptr;
+    if (pretrace) {
+      TraceParams tp{};
+      const GiQueue& q = gp.q[d & 1];
+      tp.o = q.o; tp.d = q.d; tp.m = q.m;
+      tp.hit = (uint4*)ctx->d_gi[11];
+      tp.count = gp.counts + (size_t)d * kQueueStride;
+      tp.next = traceWork + (size_t)d * 8 * kQueueStride;
+      tp.refill = refill;
+      tp.dead = d == 0 ? 1u : 0u;
+      gp.hits = tp.hit;
+      hipLaunchKernelGGL((lt_trace_kernel<kGI, false>), dim3(resident), dim3(kBlock), traceLds, s, sc, tp);
+      hipLaunchKernelGGL((lt_gi_classify_kernel<CFG>), streamGrid, streamBlock, 0, s, sc, fp, gp, (uint32_t)d);
+      hipLaunchKernelGGL((lt_gi_shadow_kernel<CFG>), streamGrid, streamBlock, 0, s, sc, fp, gp, (uint32_t)d);
+      tp.o = gp.so; tp.d = gp.sd; tp.m = gp.sm;
+      tp.count = gp.hitCount + (size_t)d * kQueueStride;
+      tp.next = shadowWork + (size_t)d * 8 * kQueueStride;
+      tp.dead = 0u;
+      hipLaunchKernelGGL((lt_trace_kernel<kGI, true>), dim3(resident), dim3(kBlock), traceLds, s, sc, tp);
+      hipLaunchKernelGGL((lt_gi_finish_kernel<CFG>), streamGrid, streamBlock, 0, s, sc, fp, gp, (uint32_t)d);
+      LT_HIP_CHECK(ctx, hipGetLastError());
+      launches += 5;
+      continue;
+    }
     if (ldsScene) {
       using CFGL = Config<false, false, CFG::kDevLibm, true>;
       hipLaunchKernelGGL((lt_gi_bounce_kernel<CFGL>), dim3((resident + kLdsSceneWaves - 1) / kLdsSceneWaves), dim3(kBlock * kLdsSceneWaves),
@@ -885,7 +986,8 @@ static int plan_fusion(lt_hip_context* ctx, const lt_hip_render_desc* d, const T
                                                                    (d->program == LT_PROGRAM_GLOBAL_ILLUMINATION && frames > 1 && d->accumulate));
   const bool giWavefront = giProgram && !stats && nblocks > 0 && (ge ? atoi(ge) == 0 : (ctx->n_prims >= 1024u || giManyLongPaths));
   const uint64_t giPixels = (uint64_t)p.tilesInCall * p.tileW * p.tileH;
-  if (giWavefront && giPixels > 0xffffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many pixels for the GI path queues");
+  const uint64_t giSlots = std::max<uint64_t>(giPixels, nblocks * kBlock);   // (a direct-mapped path queue has a slot per lane of every square)
+  if (giWavefront && giSlots > 0xffffffffull) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "too many pixels for the GI path queues");
   // Several samples of a running mean in ONE launch.  A launch cannot end before its slowest wavefront does -- one 8x8 square
   // is a dependent chain of several hundred node fetches, ~0.3-0.6 ms on the 1 M-triangle scene, 1.9 ms for the squares on
   // the image's centre column -- so a launch per sample pays that drain once per sample: 0.65 ms of a 4.5 ms launch for the
@@ -906,10 +1008,10 @@ static int plan_fusion(lt_hip_context* ctx, const lt_hip_render_desc* d, const T
     const char* fb = getenv("LT_FUSED_BYTES");
     const uint64_t cap = fb ? strtoull(fb, nullptr, 10) : (16ull << 30);
     const uint64_t frameBytes = p.floats * sizeof(float);
-    const uint64_t scratchPerFrame = frameBytes + (giWavefront ? giPixels * 16 * 11 : 0);
+    const uint64_t scratchPerFrame = frameBytes + (giWavefront ? giSlots * 16 * 17 : 0);
     if (!(fe && atoi(fe) == 0) && frameBytes > 0)
       chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(gi25Sets ? 25u : frames), cap / scratchPerFrame, 0xffffffffull / nblocks,
-                                                                  giWavefront ? 0xffffffffull / std::max<uint64_t>(giPixels, 1) : ~0ull}));
+                                                                  giWavefront ? 0xffffffffull / std::max<uint64_t>(giSlots, 1) : ~0ull}));
     if ((chunk > 1 || gi25Sets) && ctx->d_samples_bytes < chunk * frameBytes) {
       if (ctx->d_samples) LT_HIP_CHECK(ctx, hipFree(ctx->d_samples));
       ctx->d_samples = nullptr;
@@ -926,7 +1028,7 @@ static int plan_fusion(lt_hip_context* ctx, const lt_hip_render_desc* d, const T
   }
   if (giWavefront) {
     int erc;
-    while ((erc = ensure_gi_buffers(ctx, giPixels * chunk)) != LT_OK && chunk > 1) chunk /= 2;   // (frees what it got, retries smaller)
+    while ((erc = ensure_gi_buffers(ctx, giSlots * chunk)) != LT_OK && chunk > 1) chunk /= 2;   // (frees what it got, retries smaller)
     if (erc) return erc;
   }
   out.giWavefront = giWavefront;
@@ -963,10 +1065,10 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
 
   SceneDev sc;
   sc.nodes = (const float4*)ctx->d_nodes;
-  sc.own16 = ctx->d_own16 ? (const uint4*)ctx->d_own16 + 2 : nullptr;   // (behind the 32-byte grid header)
+  sc.wide = ctx->d_wide ? (const uint4*)ctx->d_wide + 4 : nullptr;   // (behind the 64 bytes that hold the grid)
   sc.ownPairs = (const float4*)ctx->d_pairs2;
   sc.rank8 = (const uint32_t*)ctx->d_rank8;
-  sc.nOwn = ctx->d_rank8 ? ctx->n_nodes2 : 0u;
+  sc.nWide = ctx->d_rank8 ? ctx->n_wide : 0u;
   sc.tris = (const float4*)ctx->d_tris;
   sc.prims = (const float*)ctx->d_prims;
   sc.mats = (const Material*)ctx->d_mats;
@@ -1078,9 +1180,10 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       uint32_t* queues = persistent ? ctx->d_queues + (size_t)launchIndex * 8 * kQueueStride : nullptr;
       // LDS stack rows: a lane never holds more entries than a node has interior ancestors (= bvh_height, validate_scene)
       // The counting kernels (and the LDS-resident small scenes of the GI bounce stage: launch_gi_sample) keep one stack entry
-      // per lane and level of the caller's tree in LDS; the others need the packet walks' two rows only (kPacketRows).
+      // per lane and level of the caller's tree in LDS; the others the kOwnRows rows of the per-lane walks over the own tree (the
+      // packet walks park their stack register in the first of them).
       ctx->lds_ref_bytes = (uint32_t)std::max(kPacketRows, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
-      uint32_t lds = stats ? ctx->lds_ref_bytes : (uint32_t)kPacketRows * kBlock * sizeof(int);
+      uint32_t lds = stats ? ctx->lds_ref_bytes : (uint32_t)std::max(kPacketRows, kOwnRows) * kBlock * sizeof(int);
       // (occupancy experiments: MORE rows than the launch needs, never fewer -- the counting kernels' per-lane stacks live there)
       if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = std::max(lds, (uint32_t)std::max(0, std::min(160, atoi(e))) * (uint32_t)(kBlock * sizeof(int)));
       if (giWavefront) {

@@ -37,6 +37,10 @@ constexpr int kQueueStride = 64;   // dwords between work counters: one 256-byte
 constexpr int kPacketEntry = 4;    // dwords per entry of a packet walk's wave-uniform stack (node reference + 64-bit lane mask, one spare)
 constexpr int kPacketRows = 2;     // ... which therefore fits 32 entries -- kLdsStack levels -- in two 256-byte rows of the wave's LDS
 constexpr int kMaxStack = 64;      // the reference's nodesToVisit[64] (acc.cl:137)
+constexpr int kOwnRows = 16;       // LDS rows (one dword per lane each) of the stack of a per-lane walk over the own tree's 4-wide groups ...
+constexpr int kOwnDeep = 48;       // ... and the entries beyond them, in private memory (the build caps the groups' height at (64 - 4) / 3)
+constexpr int kTraceRows = 10;     // lt_trace_kernel: LDS rows of its lanes' stacks (kOwnRows + kOwnDeep - kTraceRows entries in private memory) ...
+constexpr int kTraceStage = 10;    // ... and of its staged rays (origin 3, direction 4, ignored primitive, tmax, index): 20 rows = 5 KB, 32 waves per CU
 constexpr float kFltMax = 3.402823466e+38f;
 
 enum Program { kBasic = 0, kBasicLighting = 1, kAccumulator = 2, kGI = 3, kGI25 = 4, kCustom = 5,
@@ -68,19 +72,19 @@ struct SceneDev {
   // (`t < payload.t`, acc.cl:104); a walk that meets the leaves in another order keeps the one with the lower rank.  Null
   // when the walks follow the caller's tree in the reference's order themselves.
   const uint32_t* rank8;
-  uint32_t nOwn;            // nodes of the own tree
-  // The own tree as the per-lane walks read it (traverse_own_lane): ONE 16-byte record per node -- the node's box quantised to
-  // 16 bits per bound on a grid over the scene's bounds, rounded outwards (q16Origin + q * q16Step per axis), and a link: an
-  // interior node's ESCAPE index (the node that follows its subtree in pre-order, nOwn at the end: the walk needs no stack), a
-  // leaf's primitive offset with bit 31 set.  A per-lane walk is 64 different addresses per visited node, and what it saturates
-  // is the vector-memory address path -- one lane-address per clock and CU (tools/probes/gather_calib.hip) -- so a visit that is
-  // one global_load_dwordx4 instead of the two of a 32-byte node takes half the time.  Legal for the reason the packet walks'
-  // pushed-out boxes are (lt_walk_asm.hpp): only a LEAF's own box needs the reference's exact test, and that comes from the
-  // leaf's 64-byte record in ownPairs.  (A half-precision box was tried in round 2 and lost: a half carries 11 bits of the
-  // COORDINATE; 16 bits of the scene's extent are 32 times finer around coordinate 5 of a 10-unit scene.)
-  // The grid sits in front of the records: own16[-2] = (origin.xyz, -), own16[-1] = (step.xyz, -), fetched by scalar loads at the
+  // The own tree as the per-lane walks read it (traverse_own_lane): 64-byte records, nWide 4-wide groups first -- four child
+  // slots of 16 bytes: the child's box quantised to 16 bits per bound on a grid over the scene's bounds, rounded outwards, and a
+  // link (the child's own group; or 0x80000000 | record index of a leaf) -- then one leaf record per primitive offset (record
+  // nWide + offset: the leaf's own box bit for bit, its re-tiled triangle, the offset), lt_wide_kernel / lt_wide_leaf_kernel.
+  // A per-lane walk is a chain of dependent memory round trips, 64 different addresses each, and spends two thirds of its
+  // wave-cycles waiting for them (profiles/r2/gi_wall): four boxes per round trip make the chain four times shorter than the
+  // binary tree's, and 16 bytes per box cost the vector-memory address path (one lane-address per clock and CU:
+  // tools/probes/gather_calib.hip) half of what a 32-byte node does.  Legal for the reason the packet walks' pushed-out boxes
+  // are (lt_walk_asm.hpp): only a LEAF's own box needs the reference's exact test, and that comes from the leaf's record.
+  // The grid sits in front of the records: wide[-2] = (origin.xyz, -), wide[-1] = (step.xyz, -), fetched by scalar loads at the
   // start of a walk (kernel arguments occupy SGPRs for the whole kernel, and the render kernels have none to spare).
-  const uint4* own16;
+  const uint4* wide;
+  uint32_t nWide;
   const float4* tris;
   const float* prims;       // 19 floats per primitive
   const Material* mats;
@@ -560,13 +564,13 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
 }
 
 // The per-lane walk over the backend's own tree (finite rays of the non-counting kernels; lt_retree.hpp says why any order over
-// any enclosing hierarchy finds the reference's set of leaves).  No stack: the tree is in pre-order, the left child follows its
-// parent, and an interior node carries its escape index -- where the walk continues when the node's box is missed or its subtree
-// is done -- so a step is "fetch 16 bytes, conservative slab test, pick i + 1 or the escape".  A leaf whose quantised box is
-// hit is only noted; its 64-byte record (the leaf's own box bit for bit, the re-tiled triangle, the primitive offset:
-// lt_own_pair_kernel) is fetched at the top of the next step, behind the issue of that step's node load, and gets the
-// reference's own slab test and triangle test.  Closest-hit walks settle equal-t ties with the reference's leaf order
-// (SceneDev::rank8); any-hit walks (shadow rays: their callers read hitType only) stop at the first accepted hit.
+// any enclosing hierarchy finds the reference's set of leaves), collapsed into 4-wide groups (lt_retree::collapse_wide).  One
+// loop, one 64-byte record per step, whatever the record is: a group -- its four child slots are tested conservatively on their
+// 16-bit boxes and the links of those entered go on the lane's stack -- or a leaf, which gets the reference's own slab test
+// (acc.cl:113-130) of its own box and the reference's triangle test (acc.cl:72-111); then the next entry is popped.  Closest-hit
+// walks settle equal-t ties with the reference's leaf order (SceneDev::rank8); any-hit walks (shadow rays: their callers read
+// hitType only) stop at the first accepted hit.  The stack: kOwnRows dwords per lane in LDS (column `lane` of the wave's rows),
+// the rest in private memory.
 //
 // The conservative test on a quantised box [O + ql S, O + qh S] (per axis; O, S floats taken as exact reals; the build checks in
 // double that O + ql S <= lo - 8u|lo| and O + qh S >= hi + 8u|hi| for the node's true box, u = 2^-24).  Per lane, once per ray:
@@ -592,7 +596,7 @@ __device__ inline void traverse_nodes_impl(const SceneDev& sc, const Ray& ray, f
 struct Own16Ray { float sx, sy, sz, nx, ny, nz, fx, fy, fz; };   // sI; cN; cF
 __device__ __forceinline__ Own16Ray own16_ray(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz) {
   Own16Ray r;
-  const F8v fr = *(ConstF8)((unsigned long long)sc.own16 - 32ull);   // origin.xyz - step.xyz -
+  const F8v fr = *(ConstF8)((unsigned long long)sc.wide - 32ull);   // origin.xyz - step.xyz -
   const float px = ray.o.x * ix, py = ray.o.y * iy, pz = ray.o.z * iz;
   r.sx = fr.s4 * ix; r.sy = fr.s5 * iy; r.sz = fr.s6 * iz;
   const float cx = __builtin_fmaf(fr.s0, ix, -px), cy = __builtin_fmaf(fr.s1, iy, -py), cz = __builtin_fmaf(fr.s2, iz, -pz);
@@ -613,44 +617,64 @@ __device__ __forceinline__ bool own16_box_test(const uint4 q, const Own16Ray& r,
   return tF >= __builtin_fmaxf(tN, __uint_as_float(1u));
 }
 
-// the reference's own tests of a leaf noted by the walk: its box (acc.cl:113-130, finite form) and its triangle (acc.cl:72-111)
-template <int PROGRAM, bool ANYHIT>
-__device__ __forceinline__ bool own_leaf_test(const SceneDev& sc, uint32_t node, const Ray& ray, float ix, float iy, float iz, Hit& pl,
-                                              const uint32_t* rank8, uint32_t octant) {
-  const float4* r = (const float4*)((const char*)sc.ownPairs + ((size_t)node << 6));
-  const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];   // A e1.x | e1.yz e2.xy | e2.z lo | hi prim
-  // (all four loads in ONE round trip: left alone, the compiler fetches the box, tests it and only then fetches the triangle --
-  // two dependent round trips in a step that the other lanes of the wave sit through)
-  asm volatile("" ::"v"(r0.x), "v"(r1.x), "v"(r2.x), "v"(r3.x));
-  if (!box_test_finite(r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, ray, ix, iy, iz)) return false;
-  const int prim = __float_as_int(r3.w);
-  if (intersect_triangle_data<PROGRAM>(r0, r1, make_float4(r2.x, 0.0f, 0.0f, 0.0f), ray, pl, sc.fastRcp != 0u, rank8, octant, prim)) {
-    pl.prim = prim;
-    pl.hitType = 1;
-    return true;
+// One step of that walk for one lane: the record `e` (a group, or a leaf: bit 31) is fetched and dealt with, the next entry
+// popped into `e`.  Returns true when the walk is over -- the stack is empty, or an any-hit walk has accepted a hit.
+struct OwnRay {   // what a lane keeps about its ray while it walks
+  Own16Ray qr;
+  uint32_t ignLink;   // link of the leaf the ray starts on (never entered: acc.cl:188)
+  uint32_t octant;
+  bool negx, negy, negz;
+};
+__device__ __forceinline__ OwnRay own_ray(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign) {
+  OwnRay w;
+  w.qr = own16_ray(sc, ray, ix, iy, iz);
+  w.negx = ix < 0.0f; w.negy = iy < 0.0f; w.negz = iz < 0.0f;
+  w.octant = (w.negx ? 1u : 0u) | (w.negy ? 2u : 0u) | (w.negz ? 4u : 0u);
+  // (ign = -1 gives the link of a leaf record that does not exist: it equals no slot's)
+  w.ignLink = 0x80000000u | (sc.nWide + (uint32_t)ign);
+  return w;
+}
+template <int PROGRAM, bool ANYHIT, int ROWS = kOwnRows>
+__device__ __forceinline__ bool own_walk_step(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, const OwnRay& w, Hit& pl, int* col,
+                                              int* deep, uint32_t& e, int& sp) {
+  const uint4* rec = (const uint4*)((const char*)sc.wide + ((size_t)(e & 0x7fffffffu) << 6));
+  const uint4 s0 = rec[0], s1 = rec[1], s2 = rec[2], s3 = rec[3];
+  if ((int)e < 0) {   // a leaf: A e1.x | e1.yz e2.xy | e2.z lo | hi prim
+    if (box_test_finite(__uint_as_float(s2.y), __uint_as_float(s2.z), __uint_as_float(s2.w), __uint_as_float(s3.x), __uint_as_float(s3.y),
+                        __uint_as_float(s3.z), ray, ix, iy, iz)) {
+      const int prim = (int)s3.w;
+      const float4 t0 = make_float4(__uint_as_float(s0.x), __uint_as_float(s0.y), __uint_as_float(s0.z), __uint_as_float(s0.w));
+      const float4 t1 = make_float4(__uint_as_float(s1.x), __uint_as_float(s1.y), __uint_as_float(s1.z), __uint_as_float(s1.w));
+      if (intersect_triangle_data<PROGRAM>(t0, t1, make_float4(__uint_as_float(s2.x), 0.0f, 0.0f, 0.0f), ray, pl, sc.fastRcp != 0u,
+                                           ANYHIT ? nullptr : sc.rank8, w.octant, prim)) {
+        pl.prim = prim;
+        pl.hitType = 1;
+        if (ANYHIT) return true;
+      }
+    }
+  } else {
+    const uint4 slot[4] = {s0, s1, s2, s3};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (own16_box_test(slot[k], w.qr, w.negx, w.negy, w.negz) && slot[k].w != w.ignLink) {
+        if (sp < ROWS) col[sp * kBlock] = (int)slot[k].w; else deep[sp - ROWS] = (int)slot[k].w;
+        sp++;
+      }
+    }
   }
+  if (sp == 0) return true;
+  sp--;
+  e = (uint32_t)(sp < ROWS ? col[sp * kBlock] : deep[sp - ROWS]);
   return false;
 }
 
 template <int PROGRAM, bool ANYHIT>
-__device__ inline void traverse_own_lane(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl) {
-  const uint32_t octant = (ix < 0.0f ? 1u : 0u) | (iy < 0.0f ? 2u : 0u) | (iz < 0.0f ? 4u : 0u);
-  const uint32_t* const rank8 = ANYHIT ? nullptr : sc.rank8;
-  const Own16Ray qr = own16_ray(sc, ray, ix, iy, iz);
-  const uint32_t end = sc.nOwn;
-  uint32_t cur = 0u;
-  int pend = -1;   // a leaf (node index) whose quantised box was hit in the previous step
-  do {
-    const uint4 q = *(const uint4*)((const char*)sc.own16 + ((size_t)cur << 4));
-    if (pend >= 0) {
-      if (own_leaf_test<PROGRAM, ANYHIT>(sc, (uint32_t)pend, ray, ix, iy, iz, pl, rank8, octant) && ANYHIT) return;
-    }
-    const bool hit = own16_box_test(q, qr, ix < 0.0f, iy < 0.0f, iz < 0.0f);
-    const bool leaf = (int)q.w < 0;
-    pend = (hit && leaf && (int)(q.w & 0x7fffffffu) != ign) ? (int)cur : -1;
-    cur = (leaf || hit) ? cur + 1u : q.w;
-  } while (cur < end);
-  if (pend >= 0) own_leaf_test<PROGRAM, ANYHIT>(sc, (uint32_t)pend, ray, ix, iy, iz, pl, rank8, octant);
+__device__ inline void traverse_own_lane(const SceneDev& sc, const Ray& ray, float ix, float iy, float iz, int ign, Hit& pl, int* col) {
+  const OwnRay w = own_ray(sc, ray, ix, iy, iz, ign);
+  int deep[kOwnDeep];
+  int sp = 0;
+  uint32_t e = 0u;   // the root's group
+  while (!own_walk_step<PROGRAM, ANYHIT>(sc, ray, ix, iy, iz, w, pl, col, deep, e, sp)) {}
 }
 
 // Compile-time configuration of one kernel instantiation.
@@ -917,7 +941,7 @@ __device__ inline void traverse(const SceneDev& sc, const Ray& ray, bool useIgno
     }
     if constexpr (!STATS && !LDSSCENE) {
       if (ownWalks) {   // (the scene has a tree of the backend's own: lt_hip_set_scene)
-        traverse_own_lane<PROGRAM, ANYHIT>(sc, ray, ix, iy, iz, useIgnore ? ignore : -1, pl);
+        traverse_own_lane<PROGRAM, ANYHIT>(sc, ray, ix, iy, iz, useIgnore ? ignore : -1, pl, st.lds);
         return;
       }
     }
@@ -966,10 +990,11 @@ __device__ __forceinline__ const float* light_prim(const SceneDev& sc, float rnd
 
 // Light sample + shadow ray: acc.cl:239-279, basic_lighting.cl:234-274, gi.cl:267-297 and :323-349.
 // normal_w is 0 in accumulator/basic_lighting, 1 in GI (extractDataFromBarycentrics returns w = 1, gi.cl:238).
-template <int PROGRAM, class CFG>
-__device__ inline bool direct_light(const SceneDev& sc, const float* pr, int primIndex, float u, float v, float fx,
-                                    float fy, float seedIndex, float seedU, float seedV, float normal_w, V4& position,
-                                    V4& normal, float& ndotl, Stack<CFG::kDeep>& st, Counters& c) {
+// light_sample: everything up to the shadow ray -- the point on the light, the hit's position and normal, the ray towards the
+// light, its length minus the shadow epsilon (tmax) and n.l; direct_light: that, and the ray's walk.
+template <class CFG>
+__device__ __forceinline__ void light_sample(const SceneDev& sc, const float* pr, float u, float v, float fx, float fy, float seedIndex, float seedU,
+                                             float seedV, float normal_w, V4& position, V4& normal, V4& toLight, float& tmax, float& ndotl) {
   // Order of evaluation (not of arithmetic: every value is the reference's): the light sample first -- three random() calls,
   // i.e. three double-precision sin / fmod evaluations that want every register -- and only then the hit primitive's own
   // positions and normals, fenced so that the compiler does not issue those loads ahead of the randoms and carry 19 floats
@@ -992,12 +1017,22 @@ __device__ inline bool direct_light(const SceneDev& sc, const float* pr, int pri
   const V3 n3 = bary3<CFG::kDevLibm>(pr + 9, pr + 12, pr + 15, b);
   normal = mk4(n3.x, n3.y, n3.z, normal_w);
 
-  const V4 toLight = normalize4<CFG::kDevLibm>(sub4(lightPosition, position));
-  Hit spl{0, 0, (float)((double)distance4<CFG::kDevLibm>(position, lightPosition) - 0.01), 0.0f, 0.0f};
-  const Ray shadowRay{position, toLight};
+  toLight = normalize4<CFG::kDevLibm>(sub4(lightPosition, position));
+  tmax = (float)((double)distance4<CFG::kDevLibm>(position, lightPosition) - 0.01);
   // (before the walk, not after it as acc.cl:277 has it: the value does not depend on the walk, and the nine normal floats need
   // not stay in registers -- i.e. in scratch memory, 48 bytes per pixel and sample -- while it runs)
   ndotl = dot4(toLight, normal);
+}
+
+template <int PROGRAM, class CFG>
+__device__ inline bool direct_light(const SceneDev& sc, const float* pr, int primIndex, float u, float v, float fx,
+                                    float fy, float seedIndex, float seedU, float seedV, float normal_w, V4& position,
+                                    V4& normal, float& ndotl, Stack<CFG::kDeep>& st, Counters& c) {
+  V4 toLight;
+  float tmax;
+  light_sample<CFG>(sc, pr, u, v, fx, fy, seedIndex, seedU, seedV, normal_w, position, normal, toLight, tmax, ndotl);
+  Hit spl{0, 0, tmax, 0.0f, 0.0f};
+  const Ray shadowRay{position, toLight};
   asm volatile("" : "+v"(ndotl));   // (pins it here: left alone, the compiler sinks the interpolation of the normal behind the walk)
   if (CFG::kStats) c.shadow++;
   traverse<PROGRAM, CFG::kDeep, CFG::kStats, true, CFG::kLdsScene>(sc, shadowRay, true, primIndex, spl, st, c);

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(PROGRAM)) void lt_render_ker
 // re-traces the identical ray each time: same hit, same term).  Used when work is not being counted; the counting variants
 // run the one-lane-per-pixel kernel, which re-traces like the reference does.
 struct GiQueue { float4* o; float4* d; float4* n; uint4* m; };
+constexpr uint32_t kDeadPath = 0xffffffffu;   // m.x of a slot of a direct-mapped queue that holds no path
 
 struct GiParams {
   GiQueue q[2];            // ping-pong: stage d reads q[d & 1], writes q[(d + 1) & 1]
@@ -177,6 +178,20 @@ struct GiParams {
   // and every path carries its frame (m.w).
   uint32_t pixels;         // compact output pixels of one frame
   uint32_t ldsRows;        // rows of each wave's LDS stack (the stage kernels with several waves per workgroup need it)
+  // The extension rays of a stage traced ahead of it by lt_trace_kernel (below): hits[e] = (primitive, hitType, u, v) of path e
+  // of the stage's queue, or null when the stage traces them itself (small LDS-resident scenes; scenes without an own tree).
+  const uint4* hits;
+  // ... and then the stage runs as three kernels with a compacted list between them instead of one (below): the paths whose
+  // extension ray hit a surface (hitList, hitCount), their light samples and shadow rays (so = position + tmax, sd = direction,
+  // sm = (path, primitive, n.l), sn = normal), which lt_trace_kernel walks as any-hit rays (occluded: hits[i].y of the LIST entry).
+  // Queue 0 is then not appended to but DIRECT-MAPPED: the path of lane l of square p (position in the XCD-contiguous square
+  // list) and frame f sits at slot (p * frames + f) * 64 + l, dead slots (no surface hit, pixel outside the image) marked by
+  // m.x = kDeadPath.  No atomic in the camera stage (its 2 M appends to one counter were a 12 ns queue of their own), and the
+  // queue is in the squares' order: an eighth of it is an eighth of the image, which lt_trace_kernel hands to one XCD.
+  uint32_t directQueue;
+  uint32_t* hitList;
+  uint32_t* hitCount;      // [maxDepth + 1], kQueueStride dwords apart
+  float4* so; float4* sd; uint4* sm; float4* sn;
 };
 
 __device__ __forceinline__ bool square_pixel(const FrameParams& fp, uint32_t b, uint32_t& x, uint32_t& y, uint32_t& pix) {
@@ -211,6 +226,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_primary_kerne
   Counters c{};
   const uint32_t n = fp.totalSquares, q = n / 8u, r = n % 8u;
   const uint32_t home = __builtin_amdgcn_s_getreg((3u << 11) | 20u) & 7u;
+  if (gp.directQueue && blockIdx.x == 0 && threadIdx.x == 0) gp.counts[0] = n * fp.fusedFrames * (uint32_t)kBlock;   // (read by the launches behind this one)
   for (uint32_t sweep = 0; sweep < 8u;) {
     const uint32_t xcd = (home + sweep) & 7u;
     const uint32_t share = q + (xcd < r ? 1u : 0u), start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
@@ -251,7 +267,13 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_primary_kerne
       gp.direct[pix] = make_float4(direct.x, direct.y, direct.z, 0.0f);
       gp.indirect[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    const uint32_t slot = wave_append(&gp.counts[0], alive);
+    uint32_t slot;
+    if (gp.directQueue) {
+      slot = ((start + t) * fp.fusedFrames + frame) * (uint32_t)kBlock + threadIdx.x;
+      if (!alive) gp.q[0].m[slot].x = kDeadPath;
+    } else {
+      slot = wave_append(&gp.counts[0], alive);
+    }
     if (alive) {
       gp.q[0].o[slot] = make_float4(position.x, position.y, position.z, fx);
       gp.q[0].d[slot] = make_float4(dir.x, dir.y, dir.z, dir.w);
@@ -314,7 +336,12 @@ void lt_gi_bounce_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t dept
       const Ray ext{mk4(o.x, o.y, o.z, 1.0f), mk4(dd.x, dd.y, dd.z, dd.w)};
       const V4 previousNormal = mk4(nn.x, nn.y, nn.z, nn.w);
       Hit epl{0, 0, kFltMax, 0.0f, 0.0f};
-      traverse<kGI, CFG::kDeep, false, false, CFG::kLdsScene>(sc, ext, true, (int)misc.y, epl, st, c);
+      if (gp.hits != nullptr) {   // traced ahead of this launch by lt_trace_kernel (t is not read below)
+        const uint4 h = gp.hits[e];
+        epl.prim = (int)h.x; epl.hitType = (int)h.y; epl.u = __uint_as_float(h.z); epl.v = __uint_as_float(h.w);
+      } else {
+        traverse<kGI, CFG::kDeep, false, false, CFG::kLdsScene>(sc, ext, true, (int)misc.y, epl, st, c);
+      }
       const uint32_t s = gp.sample + misc.w, sd = s + depth;
       float4 ind = gp.indirect[pix];
       if (is_light(sc.lights, epl.prim)) {
@@ -351,6 +378,269 @@ void lt_gi_bounce_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t dept
       out.d[slot] = make_float4(ndir.x, ndir.y, ndir.z, ndir.w);
       out.n[slot] = make_float4(enorm.x, enorm.y, enorm.z, enorm.w);
       out.m[slot] = make_uint4(misc.x, (uint32_t)hitPrim, misc.z, misc.w);
+    }
+  }
+}
+
+// ---- a bounce stage in pieces, around lt_trace_kernel (further down), when its extension rays were traced ahead of it:
+//   lt_gi_classify_kernel : every path of the stage's queue: a light hit adds its terms (gi.cl:319-321); a surface hit joins the list
+//   lt_gi_shadow_kernel   : every path of the list: the light sample (gi.cl:323-349) and its shadow ray, into the shadow queue
+//   (lt_trace_kernel, any-hit, over the shadow queue)
+//   lt_gi_finish_kernel   : every path of the list whose shadow ray found nothing: the indirect term, the next extension ray
+//                           (gi.cl:350-366), appended to the next stage's queue
+// Same arithmetic per path as lt_gi_bounce_kernel, same order of a pixel's terms (one path per pixel and frame).  What it buys:
+// on the 1 M-triangle wall nine extension rays in ten hit nothing, and a wavefront of the one-kernel stage ran the light
+// sampling (three double-precision random() calls) and a per-lane shadow walk for the few lanes that did; here those lanes of
+// all wavefronts are packed into full wavefronts first.
+// (kClassifyBatch paths per lane and list append: an atomic on ONE address completes every ~12 ns chip-wide, and one per 64 paths
+// made this kernel -- 16 bytes in, at most 4 out per path -- take 33 ms for the 133 M paths of the 1 M-triangle wall's first stage)
+constexpr int kClassifyBatch = 8;
+template <class CFG>
+__global__ __launch_bounds__(256) void lt_gi_classify_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t depth) {
+  const GiQueue in = gp.q[depth & 1u];
+  const uint32_t total = gp.counts[depth * kQueueStride];
+  const uint32_t lane = threadIdx.x % kBlock, wave = (blockIdx.x * blockDim.x + threadIdx.x) / kBlock, waves = gridDim.x * blockDim.x / kBlock;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (uint64_t base = (uint64_t)wave * (kBlock * kClassifyBatch); base < total; base += (uint64_t)waves * (kBlock * kClassifyBatch)) {
+    bool surface[kClassifyBatch];
+    uint32_t before[kClassifyBatch];   // surface hits of this wave's batch in front of this lane's k-th path
+    uint32_t count = 0u;
+#pragma unroll
+    for (int k = 0; k < kClassifyBatch; k++) {
+      const uint64_t e = base + (uint64_t)k * kBlock + lane;
+      surface[k] = false;
+      if (e < total && !(gp.directQueue && depth == 0u && in.m[e].x == kDeadPath)) {
+        const uint4 h = gp.hits[e];
+        if (is_light(sc.lights, (int)h.x)) {
+          // the reference keeps looping with the SAME ray (gi.cl:319-321): same hit, one more term per remaining depth
+          const float4 dd = in.d[e], nn = in.n[e];
+          const uint32_t pix = in.m[e].x;
+          const float kk = dot4(mk4(nn.x, nn.y, nn.z, nn.w), mk4(dd.x, dd.y, dd.z, dd.w));
+          float4 ind = gp.indirect[pix];
+          for (int dd2 = (int)depth; dd2 < fp.giMaxDepth; dd2++) {
+            const float w = (float)(1.0 / (double)(dd2 + 1));
+            ind.x = Math<CFG::kDevLibm>::mad(w * 1.0f, kk, ind.x);
+            ind.y = Math<CFG::kDevLibm>::mad(w * 1.0f, kk, ind.y);
+            ind.z = Math<CFG::kDevLibm>::mad(w * 1.0f, kk, ind.z);
+          }
+          gp.indirect[pix] = ind;
+        } else {
+          surface[k] = h.y == 1u;
+        }
+      }
+      const unsigned long long m = __ballot(surface[k]);
+      before[k] = count + (uint32_t)__popcll(m & below);
+      count += (uint32_t)__popcll(m);
+    }
+    if (count == 0u) continue;
+    uint32_t slot0 = 0u;
+    if (lane == 0u) slot0 = atomicAdd(&gp.hitCount[depth * kQueueStride], count);
+    slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+#pragma unroll
+    for (int k = 0; k < kClassifyBatch; k++)
+      if (surface[k]) gp.hitList[slot0 + before[k]] = (uint32_t)(base + (uint64_t)k * kBlock + lane);
+  }
+}
+
+template <class CFG>
+__global__ __launch_bounds__(256) void lt_gi_shadow_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t depth) {
+  const GiQueue in = gp.q[depth & 1u];
+  const uint32_t total = gp.hitCount[depth * kQueueStride];
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const uint32_t e = gp.hitList[i];
+    const uint4 h = gp.hits[e], misc = in.m[e];
+    const float fx = in.o[e].w, fy = __uint_as_float(misc.z);
+    const uint32_t sd = gp.sample + misc.w + depth;
+    V4 epos, enorm, toLight;
+    float tmax, endotl;
+    light_sample<CFG>(sc, prim_ptr(sc, (int)h.x), __uint_as_float(h.z), __uint_as_float(h.w), fx, fy, (float)(sd + 5u), (float)(sd + 6u), (float)(sd + 7u),
+                      1.0f, epos, enorm, toLight, tmax, endotl);
+    gp.so[i] = make_float4(epos.x, epos.y, epos.z, tmax);
+    gp.sd[i] = make_float4(toLight.x, toLight.y, toLight.z, toLight.w);
+    gp.sm[i] = make_uint4(e, h.x, __float_as_uint(endotl), 0u);
+    gp.sn[i] = make_float4(enorm.x, enorm.y, enorm.z, enorm.w);
+  }
+}
+
+template <class CFG>
+__global__ __launch_bounds__(256) void lt_gi_finish_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t depth) {
+  const GiQueue in = gp.q[depth & 1u], out = gp.q[(depth + 1u) & 1u];
+  const uint32_t total = gp.hitCount[depth * kQueueStride];
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const int d = (int)depth;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += stride) {   // (whole wavefronts take part in wave_append)
+    const uint32_t i = base + threadIdx.x;
+    bool alive = false;
+    V4 ndir{};
+    float4 so = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sn = so;
+    uint4 sm = make_uint4(0u, 0u, 0u, 0u), misc = sm;
+    float fx = 0.0f;
+    if (i < total && gp.hits[i].y == 0u) {   // the shadow ray found nothing (gi.cl:351)
+      so = gp.so[i]; sn = gp.sn[i]; sm = gp.sm[i];
+      const uint32_t e = sm.x;
+      misc = in.m[e];
+      fx = in.o[e].w;
+      const float fy = __uint_as_float(misc.z);
+      const uint32_t pix = misc.x, sd = gp.sample + misc.w + depth;
+      const float w = (float)(1.0 / (double)(d + 1));
+      const Material* em = sc.mats + prim_material(prim_ptr(sc, (int)sm.y));
+      const float endotl = __uint_as_float(sm.z);
+      float4 ind = gp.indirect[pix];
+      ind.x = Math<CFG::kDevLibm>::mad(w * em->diffuse[0], endotl, ind.x);
+      ind.y = Math<CFG::kDevLibm>::mad(w * em->diffuse[1], endotl, ind.y);
+      ind.z = Math<CFG::kDevLibm>::mad(w * em->diffuse[2], endotl, ind.z);
+      gp.indirect[pix] = ind;
+      const V4 hemi = uniform_sample_hemisphere<CFG::kDevLibm>(random_<CFG::kDevLibm>(fx, fy, (float)(sd + 8u)), random_<CFG::kDevLibm>(fx, fy, (float)(sd + 9u)));
+      ndir = align_hemisphere<CFG::kDevLibm>(hemi, mk4(sn.x, sn.y, sn.z, sn.w));
+      alive = d + 1 < fp.giMaxDepth;
+    }
+    const uint32_t slot = wave_append(&gp.counts[(depth + 1u) * kQueueStride], alive);
+    if (alive) {
+      out.o[slot] = make_float4(so.x, so.y, so.z, fx);
+      out.d[slot] = make_float4(ndir.x, ndir.y, ndir.z, ndir.w);
+      out.n[slot] = sn;
+      out.m[slot] = make_uint4(misc.x, sm.y, misc.z, misc.w);
+    }
+  }
+}
+
+// =====================================================================================================================
+// lt_trace_kernel: a queue of rays through the per-lane walk over the own tree (lt_device.hpp: own_walk_step), with LANE REFILL.
+// Incoherent rays differ in cost by two orders of magnitude -- a bounce ray that leaves the 1 M-triangle wall visits a handful
+// of groups, one that grazes it several hundred leaves -- and a wavefront that walks 64 of them side by side runs until its
+// slowest lane is done (measured on that scene's bounce stage: 14-17 % of the lanes active in the average vector instruction,
+// profiles/r2/gi_wall, gpurun_out r3).  Here a lane whose ray is done takes the next ray of the queue: whenever at least
+// `refill` lanes of the wave are idle (or all of them), the idle lanes claim that many rays with ONE atomic (ballot, popcount,
+// prefix count) and set them up; then every lane with a ray makes one step.  A lane's state is its ray and its stack, nothing
+// of the shading that produced the ray or will consume the hit: that is why this is a kernel of its own.
+//   rays:   o[i] = (origin.xyz, tmax of an any-hit ray), d[i] = direction.xyzw, m[i].y = the primitive the ray starts on (ignored,
+//           acc.cl:188)
+//   result: hit[i] = (primitive, hitType, u, v)    (t is not kept: no caller reads it; an any-hit ray's caller reads hitType only)
+// Rays the walks over the own tree do not take (a non-finite component, magnitudes beyond packet_ray_ok) are walked at once, in
+// the reference's order over the caller's tree, by the lane that drew them.  Every wave reaches the exit: the queue hands out
+// each index once, a lane's walk ends (the stack only holds entries of a finite tree), and the loop ends when the queue is drained
+// and no lane holds a ray.
+constexpr int kTraceClaim = 512;   // rays a wave claims from the queue per atomic
+struct TraceParams {
+  const float4* o;
+  const float4* d;
+  const uint4* m;
+  uint4* hit;
+  const uint32_t* count;   // rays in the queue (device memory: written by the stage that filled it)
+  uint32_t* next;          // work counters (zeroed by the host): one per eighth of the queue, kQueueStride dwords apart
+  uint32_t refill;         // idle lanes that trigger a refill
+  uint32_t dead;           // != 0: the queue is direct-mapped, slots with m.x == kDeadPath hold no ray
+};
+
+template <int PROGRAM, bool ANYHIT>
+__global__ __launch_bounds__(kBlock, 8) void lt_trace_kernel(SceneDev sc, TraceParams tp) {
+  using u64 = unsigned long long;
+  extern __shared__ int lds_stack[];   // [kTraceRows stack rows][kTraceStage rows of staged rays], 64 lanes each
+  int* const col = lds_stack + threadIdx.x;
+  int* const stage = lds_stack + kTraceRows * kBlock;
+  const uint32_t total = tp.count[0];
+  const uint32_t lane = threadIdx.x;
+  const u64 below = (1ull << lane) - 1ull;
+  // (a short queue is shared out in small claims, so that it is not a few waves' work; a long one in claims of kTraceClaim)
+  const uint32_t share = total / (gridDim.x * 4u) / (uint32_t)kBlock * (uint32_t)kBlock;
+  const uint32_t claim = share < (uint32_t)kBlock ? (uint32_t)kBlock : (share > (uint32_t)kTraceClaim ? (uint32_t)kTraceClaim : share);
+  bool active = false;
+  // the wave's staged batch of rays: stageCount of them (each with its index in the queue), the first stageTaken handed out; they
+  // come out of the wave's claim [claimNext, claimEnd) of the queue (kTraceClaim rays per atomic: one address serves an atomic
+  // every ~12 ns, 80 M per second chip-wide)
+  uint32_t stageCount = 0u, stageTaken = 0u, claimNext = 0u, claimEnd = 0u, sweep = 0u;
+  const uint32_t home = __builtin_amdgcn_s_getreg((3u << 11) | 20u) & 7u;   // HW_REG_XCC_ID
+  bool drained = false;   // the queue has handed out its last ray, and the wave's claim is staged
+  Ray ray{};
+  float ix = 0.0f, iy = 0.0f, iz = 0.0f;
+  OwnRay w{};
+  Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
+  uint32_t idx = 0u, e = 0u;
+  int sp = 0;
+  int deep[kOwnRows + kOwnDeep - kTraceRows];
+  for (;;) {
+    const u64 idle = __builtin_amdgcn_ballot_w64(!active);
+    const uint32_t nIdle = (uint32_t)__popcll(idle);
+    if ((nIdle >= tp.refill || nIdle == (uint32_t)kBlock) && (stageTaken < stageCount || !drained)) {
+      if (stageTaken == stageCount) {
+        // the next 64 rays of the queue, one per lane (coalesced), parked in LDS: the lanes' own registers hold their walks
+        // The queue in eighths, one per XCD (an eighth of a direct-mapped queue is an eighth of the image: the XCD's L2 then
+        // serves the groups and leaves of one part of the scene): a wave claims from the eighth of the XCD it runs on, then from
+        // the others'.
+        while (claimNext == claimEnd && sweep < 8u) {
+          const uint32_t part = (home + sweep) & 7u;
+          const uint32_t lo = (uint32_t)((uint64_t)total * part / 8u / kBlock * kBlock), hi = part == 7u ? total : (uint32_t)((uint64_t)total * (part + 1u) / 8u / kBlock * kBlock);
+          uint32_t got = 0u;
+          if (lane == 0u) got = atomicAdd(&tp.next[part * kQueueStride], claim);
+          got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+          if (got >= hi - lo) { sweep++; continue; }
+          claimNext = lo + got;
+          claimEnd = hi - claimNext < claim ? hi : claimNext + claim;
+        }
+        const uint32_t base = claimNext;
+        const uint32_t batch = claimEnd - base < (uint32_t)kBlock ? claimEnd - base : (uint32_t)kBlock;
+        claimNext = base + batch;
+        drained = claimNext == claimEnd && sweep >= 8u;
+        stageTaken = 0u;
+        float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), dd = o;
+        uint32_t ign = 0u;
+        bool live = lane < batch;
+        if (live) {
+          const uint2 mm = *(const uint2*)&tp.m[base + lane];
+          ign = mm.y;
+          live = !(tp.dead && mm.x == kDeadPath);
+        }
+        if (live) { o = tp.o[base + lane]; dd = tp.d[base + lane]; }
+        const u64 lm = __builtin_amdgcn_ballot_w64(live);
+        stageCount = (uint32_t)__popcll(lm);
+        if (live) {
+          const uint32_t at = (uint32_t)__popcll(lm & below);
+          stage[0 * kBlock + at] = __float_as_int(o.x); stage[1 * kBlock + at] = __float_as_int(o.y); stage[2 * kBlock + at] = __float_as_int(o.z);
+          stage[3 * kBlock + at] = __float_as_int(dd.x); stage[4 * kBlock + at] = __float_as_int(dd.y); stage[5 * kBlock + at] = __float_as_int(dd.z);
+          stage[6 * kBlock + at] = __float_as_int(dd.w); stage[7 * kBlock + at] = (int)ign;
+          stage[8 * kBlock + at] = __float_as_int(o.w);   // tmax of an any-hit ray
+          stage[9 * kBlock + at] = (int)(base + lane);
+        }
+        // (one wavefront per workgroup: its own LDS writes are visible to it once they have completed -- the reads below wait for them)
+      }
+      const uint32_t take = nIdle < stageCount - stageTaken ? nIdle : stageCount - stageTaken;
+      const uint32_t mine = (uint32_t)__popcll(idle & below);
+      if (!active && mine < take) {
+        const uint32_t s = stageTaken + mine;
+        idx = (uint32_t)stage[9 * kBlock + s];
+        ray = Ray{mk4(__int_as_float(stage[0 * kBlock + s]), __int_as_float(stage[1 * kBlock + s]), __int_as_float(stage[2 * kBlock + s]), 1.0f),
+                  mk4(__int_as_float(stage[3 * kBlock + s]), __int_as_float(stage[4 * kBlock + s]), __int_as_float(stage[5 * kBlock + s]),
+                      __int_as_float(stage[6 * kBlock + s]))};
+        const int ign = stage[7 * kBlock + s];
+        ix = 1.0f / ray.d.x; iy = 1.0f / ray.d.y; iz = 1.0f / ray.d.z;
+        pl = Hit{0, 0, ANYHIT ? __int_as_float(stage[8 * kBlock + s]) : kFltMax, 0.0f, 0.0f};
+        const bool finite = __builtin_fabsf(ix) < __builtin_inff() && __builtin_fabsf(iy) < __builtin_inff() && __builtin_fabsf(iz) < __builtin_inff() &&
+                            __builtin_fabsf(ray.o.x) < __builtin_inff() && __builtin_fabsf(ray.o.y) < __builtin_inff() &&
+                            __builtin_fabsf(ray.o.z) < __builtin_inff();
+        if (finite && packet_ray_ok(ray, ix, iy, iz)) {
+          w = own_ray(sc, ray, ix, iy, iz, ign);
+          e = 0u;
+          sp = 0;
+          active = true;
+        } else {   // (rare) the reference's order over the caller's tree, here and now
+          ScratchStack ss;
+          Counters c{};
+          traverse_nodes_impl<PROGRAM, ScratchStack, false, false, ANYHIT, false>(sc, ray, ix, iy, iz, true, ign, pl, ss, c);
+          tp.hit[idx] = make_uint4((uint32_t)pl.prim, (uint32_t)pl.hitType, __float_as_uint(pl.u), __float_as_uint(pl.v));
+        }
+      }
+      stageTaken += take;
+    }
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
+      if (drained && stageTaken == stageCount) break;
+      continue;
+    }
+    if (active) {
+      if (own_walk_step<PROGRAM, ANYHIT, kTraceRows>(sc, ray, ix, iy, iz, w, pl, col, deep, e, sp)) {
+        tp.hit[idx] = make_uint4((uint32_t)pl.prim, (uint32_t)pl.hitType, __float_as_uint(pl.u), __float_as_uint(pl.v));
+        active = false;
+      }
     }
   }
 }

@@ -1,6 +1,6 @@
-// lt_own16.hpp -- the 16-byte nodes of the per-lane walks (SceneDev::own16, traverse_own_lane in lt_device.hpp): how a node of
-// the backend's own tree is put on a 16-bit grid over the scene's bounds.  Host and device share this arithmetic
-// (lt_own16_kernel at upload; lt_hip_own_quantised on the host for the CPU tests).
+// lt_own16.hpp -- the 16-byte child slots of the per-lane walks' 4-wide groups (SceneDev::wide, traverse_own_lane in
+// lt_device.hpp): how a node of the backend's own tree is put on a 16-bit grid over the scene's bounds.  Host and device share
+// this arithmetic (lt_wide_kernel at upload; lt_hip_own_wide on the host for the CPU tests).
 #pragma once
 #include <stdint.h>
 
@@ -57,17 +57,21 @@ LT_HD inline bool quantise(float lo, float hi, float Of, float Sf, uint32_t& ql,
   return ok;
 }
 
-// One node (the own tree's 32-byte form with the escape index in `off`) -> its 16-byte record.
+// One child slot of a 4-wide group (lt_retree::collapse_wide): the child's box on the grid + its link -- the child's own group
+// for an interior node; 0x80000000 | (groups + primitive offset), the index of the leaf's 64-byte record behind the groups, for a
+// leaf; an empty slot gets a box no ray can enter (lo = 65535, hi = 0) and the link of the record behind the last primitive's,
+// whose box is NaN: should arithmetic ever let a ray into the slot, the exact test of that record turns it away.
 struct Rec { uint32_t x, y, z, w; };
-LT_HD inline bool node_record(const float* lo, const float* hi, uint32_t link, bool leaf, const float* O, const float* S, Rec& r) {
+LT_HD inline bool slot_record(const float* lo, const float* hi, uint32_t link, const float* O, const float* S, Rec& r) {
   uint32_t ql[3], qh[3];
   bool ok = true;
   for (int k = 0; k < 3; k++) ok = quantise(lo[k], hi[k], O[k], S[k], ql[k], qh[k]) && ok;
   r.x = ql[0] | (ql[1] << 16);
   r.y = ql[2] | (qh[0] << 16);
   r.z = qh[1] | (qh[2] << 16);
-  r.w = link | (leaf ? 0x80000000u : 0u);
+  r.w = link;
   return ok;
 }
+LT_HD inline Rec empty_slot(uint32_t groups, uint32_t n_prims) { return Rec{0xffffffffu, 0x0000ffffu, 0u, 0x80000000u | (groups + n_prims)}; }
 
 }  // namespace lt_own16

@@ -164,7 +164,7 @@ def test_wavefront_gi_fused_chunks_and_tiles(renderer, cornell, monkeypatch):
     monkeypatch.setenv("LT_GI_MEGAKERNEL", "0")
     W, H, count, depth = 100, 70, 5, 4
     whole, _ = frames(renderer, cornell, GI, W, H, 1, count, giMaxDepth=depth)
-    per_frame = W * H * (3 * 4 + 16 * 11)
+    per_frame = W * H * 3 * 4 + ((W + 7) // 8) * ((H + 7) // 8) * 64 * 16 * 17    # the sample image + 17 arrays of 16 bytes per path slot
     monkeypatch.setenv("LT_FUSED_BYTES", str(2 * per_frame + 64))     # two frames per chunk: 2 + 2 + 1
     chunked, st = frames(renderer, cornell, GI, W, H, 1, count, giMaxDepth=depth)
     assert st["kernel_launches"] == 3 * (depth + 2)
@@ -199,7 +199,7 @@ def test_wavefront_gi25_sample_sets(renderer, cornell, monkeypatch):
     got, launches = once()
     assert launches == depth + 2                       # all 25 samples in one set of launches
     assert np.array_equal(got, want)
-    per_sample = W * H * (3 * 4 + 16 * 11)
+    per_sample = W * H * 3 * 4 + ((W + 7) // 8) * ((H + 7) // 8) * 64 * 16 * 17
     monkeypatch.setenv("LT_FUSED_BYTES", str(7 * per_sample + 8))      # 7 + 7 + 7 + 4 samples per set
     got, launches = once()
     assert launches == 4 * (depth + 2)

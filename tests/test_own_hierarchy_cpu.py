@@ -6,7 +6,9 @@ lt_walk_asm.hpp), through the host-only entry point lt_hip_own_hierarchy:
 * the order table (rank8) is the reference's depth-first, near-child-first leaf order (acc.cl:150-160) for each of the eight
   direction-sign octants;
 * the packet walks' conservative interior test accepts whenever the reference's slab test (acc.cl:113-130) does, on random and
-  on adversarial (boundary-grazing) rays -- the inequality proved in lt_walk_asm.hpp, tried in float32 arithmetic."""
+  on adversarial (boundary-grazing) rays -- the inequality proved in lt_walk_asm.hpp, tried in float32 arithmetic;
+* the per-lane walks' 4-wide groups (lt_hip_own_wide) hold every node of the tree once, their 16-bit child boxes enclose the
+  true ones, and the test on a quantised box accepts whenever the reference's accepts the true box (lt_device.hpp)."""
 import numpy as np
 import pytest
 
@@ -222,29 +224,89 @@ def random_boxes(rng, n, scale, centre):
     return (c - half).astype(f32), (c + half).astype(f32)
 
 
+def wide_children(own, slots, n_prims):
+    """The binary node behind every child slot of every group, by walking the groups from the root: (child[g, k] or -1,
+    group_of_node) -- and the structural checks on the way."""
+    G = len(slots)
+    leaf = own["primitiveCount"] != 0
+    child = np.full((G, 4), -1, dtype=np.int64)
+    node_of_group = np.full(G, -1, dtype=np.int64)
+    node_of_group[0] = 0
+    leaf_node_of_prim = {int(own["offset"][i]): i for i in np.flatnonzero(leaf)}
+    seen_leaves = 0
+    for g in range(G):                                   # depth-first numbering: a group's children have larger numbers
+        b = int(node_of_group[g])
+        assert b >= 0 and not leaf[b], "group %d is not reachable from the root" % g
+        # the (up to four) nodes the group must hold: b's two children, with up to two of them replaced by their own children
+        for k in range(4):
+            link = int(slots["link"][g, k])
+            if link == (0x80000000 | (G + n_prims)):      # empty slot: a box no ray enters
+                assert tuple(slots["q"][g, k]) == (65535, 65535, 65535, 0, 0, 0)
+                continue
+            if link & 0x80000000:
+                prim = (link & 0x7fffffff) - G
+                assert 0 <= prim < n_prims
+                child[g, k] = leaf_node_of_prim[prim]
+                seen_leaves += 1
+            else:
+                assert g < link < G and node_of_group[link] < 0
+                child[g, k] = -2                          # resolved below
+        # which interior nodes do the linked groups stand for?  b's descendants within two dissolves, in slot order
+        frontier = [b + 1, int(own["offset"][b])]
+        want = set()
+        for _ in range(2):
+            cand = [x for x in frontier if not leaf[x]]
+            if not cand or len(frontier) >= 4:
+                break
+            ext = (own["boundsMax"][cand].astype(np.float32) - own["boundsMin"][cand].astype(np.float32))
+            area = ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0]
+            x = cand[int(np.argmax(area))]
+            frontier[frontier.index(x)] = x + 1
+            frontier.append(int(own["offset"][x]))
+        interior = [x for x in frontier if not leaf[x]]
+        leaves = [x for x in frontier if leaf[x]]
+        ks = [k for k in range(4) if child[g, k] == -2]
+        assert len(ks) == len(interior) and sorted(int(c) for c in child[g] if c >= 0) == sorted(leaves)
+        for k, x in zip(ks, interior):
+            child[g, k] = x
+            node_of_group[int(slots["link"][g, k])] = x
+        # leaves sit behind the interior children
+        kinds = [bool(leaf[c]) for c in child[g] if c >= 0]
+        assert kinds == sorted(kinds)
+    assert seen_leaves == int(leaf.sum())
+    return child
+
+
 @pytest.mark.parametrize("scale,centre", [(1.0, 0.0), (1e-3, 0.0), (50.0, 10.0), (1.0, 3000.0), (1e6, 0.0)])
-def test_quantised_nodes_enclose_their_boxes_and_keep_the_links(scale, centre):
+def test_wide_groups_hold_the_tree_and_their_slots_enclose_the_boxes(scale, centre):
     rng = np.random.default_rng(11)
     lo, hi = random_boxes(rng, 3000, scale, centre)
     h, own, _ = C.own_hierarchy(chain_tree(lo, hi), len(lo), 2)
     assert h >= 0
-    O, S, rec = C.own_quantised(own)
-    q = rec["q"].astype(np.float64)
+    hw, O, S, slots = C.own_wide(own, len(lo))
+    child = wide_children(own, slots, len(lo))
+    assert 0 < hw <= h and len(slots) <= len(lo) - 1
+    used = child >= 0
+    q = slots["q"][used].astype(np.float64)
     L = O.astype(np.float64) + q[:, :3] * S.astype(np.float64)
     H = O.astype(np.float64) + q[:, 3:] * S.astype(np.float64)
-    blo, bhi = own["boundsMin"].astype(np.float64), own["boundsMax"].astype(np.float64)
+    blo, bhi = own["boundsMin"][child[used]].astype(np.float64), own["boundsMax"][child[used]].astype(np.float64)
     u = 2.0 ** -24
     assert np.all(L <= blo - 8 * u * np.abs(blo)) and np.all(H >= bhi + 8 * u * np.abs(bhi))
     # ... and tightly: at most two grid steps and 2^-20 of the bound away
     assert np.all(blo - L <= 2 * S + 2.0 ** -20 * np.abs(blo) + 1e-44) and np.all(H - bhi <= 2 * S + 2.0 ** -20 * np.abs(bhi) + 1e-44)
-    leaf = own["primitiveCount"] != 0
-    assert np.array_equal(rec["link"][leaf], own["offset"][leaf].astype(np.uint32) | np.uint32(0x80000000))
-    # an interior node's link is its escape: the node after its subtree in pre-order
-    n = len(own)
-    esc = np.zeros(n, dtype=np.int64)
-    for i in range(n - 1, -1, -1):
-        esc[i] = i + 1 if leaf[i] else esc[int(own["offset"][i])]
-    assert np.array_equal(rec["link"][~leaf].astype(np.int64), esc[~leaf])
+
+
+def test_two_leaves_on_one_primitive_get_no_wide_groups():
+    rng = np.random.default_rng(2)
+    lo, hi = random_boxes(rng, 50, 1.0, 0.0)
+    nodes = chain_tree(lo, hi)
+    leaves = np.flatnonzero(nodes["primitiveCount"] != 0)
+    nodes["offset"][leaves[7]] = nodes["offset"][leaves[3]]
+    h, own, _ = C.own_hierarchy(nodes, len(lo), 2)
+    assert h >= 0
+    with pytest.raises(C.LensTraceError):
+        C.own_wide(own, len(lo))
 
 
 def own16_test(O, S, q, o, inv):
@@ -270,11 +332,13 @@ def test_quantised_test_accepts_whenever_the_reference_accepts_the_true_box(scal
     rng = np.random.default_rng(5)
     lo, hi = random_boxes(rng, 4000, scale, centre)
     _, own, _ = C.own_hierarchy(chain_tree(lo, hi), len(lo), 2)
-    O, S, rec = C.own_quantised(own)
+    _, O, S, slots = C.own_wide(own, len(lo))
+    child = wide_children(own, slots, len(lo))
+    used = child >= 0
     reps = 60
-    idx = np.tile(np.arange(len(own)), reps)
+    idx = np.tile(np.arange(int(used.sum())), reps)
     n = len(idx)
-    blo, bhi, q = own["boundsMin"][idx], own["boundsMax"][idx], rec["q"][idx]
+    blo, bhi, q = own["boundsMin"][child[used]][idx], own["boundsMax"][child[used]][idx], slots["q"][used][idx]
     o = (centre + rng.uniform(-scale, scale, (n, 3)) * rng.choice([1.0, 3.0, 100.0], (n, 1))).astype(f32)
     w = rng.choice([0.0, 1.0, 0.5], (n, 3))                       # aim at the box's faces, edges and corners, a few ulps off
     target = (blo * (1 - w) + bhi * w).astype(f32)
