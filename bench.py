@@ -41,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SHADOW_WALKS = {0: "per lane", 1: "any-hit packets", 2: "chosen per wavefront"}   # lt_hip_stats.shadow_packets
+SHADOW_WALKS = {0: "per lane", 1: "any-hit packets", 2: "chosen per wavefront", 3: "queued for the trace kernel"}   # lt_hip_stats.shadow_packets
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 

@@ -139,13 +139,14 @@ typedef struct lt_hip_stats {
   float kernel_ms;              /* HIP-event time over the kernels of the last call, on the call's stream */
   float total_ms;               /* lt_hip_render only: upload + kernels + read-back wall time */
   float render_ms;              /* kernel_ms without the running-mean kernels that follow fused multi-sample launches */
-  int32_t shadow_packets;       /* how the last call walked its shadow rays: 1 = any-hit packets, 0 = per lane, 2 = chosen per wavefront
-                                 * (picked per scene, program and image geometry by timing the three once; LT_SHADOW_PACKETS=0/1/2
-                                 * forces), -1 = not timed yet */
+  int32_t shadow_packets;       /* how the last call walked its shadow rays: 1 = any-hit packets, 0 = per lane, 2 = chosen per wavefront,
+                                 * 3 = queued and walked by a kernel of their own whose lanes take a new ray when theirs is done
+                                 * (accumulator; picked per scene, program, image geometry and frames per launch by timing the
+                                 * candidates once; LT_SHADOW_PACKETS=0/1/2/3 forces), -1 = not timed yet */
   uint32_t scene_uploads;       /* lt_hip_set_scene calls of this context that uploaded ... */
   uint32_t scene_reused;        /* ... and those that found the resident scene's content unchanged (full hash) and kept it */
   int32_t own_tree_height;      /* height of the backend's own hierarchy over the scene's leaves (built at lt_hip_set_scene, walked by
-                                 * shadow rays; LT_RETREE=0 turns it off), -1 = none: every walk uses the caller's tree */
+                                 * every finite ray of the non-counting kernels; LT_RETREE=0 keeps the caller's splits), -1 = none: every walk uses the caller's tree */
   float own_tree_ms;            /* host time of that build */
 } lt_hip_stats;
 

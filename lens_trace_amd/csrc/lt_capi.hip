@@ -181,6 +181,9 @@ struct lt_hip_context {
   int shadow_mode[6] = {-1, -1, -1, -1, -1, -1};   // per built-in program: shadow rays as any-hit packets (1) or per lane (0); -1 = not timed yet
   hipEvent_t cal_ev[12] = {};
   std::map<std::vector<uint32_t>, int> shadow_modes;   // (program, W, H, tile geometry) -> the walk timed faster for it on the resident scene
+  void* d_shadowq = nullptr;         // accumulator's queued shadow rays (shadow mode 3): origin+tmax, direction, (pixel, primitive, frame), hit: 64 bytes per slot
+  uint64_t shadowq_slots = 0;
+  uint32_t* d_shadowCtl = nullptr;   // ... the trace launch's eight work counters (kQueueStride apart) and, behind them, the queue's length
   float* d_samples = nullptr;        // un-accumulated sample images of a fused multi-sample launch
   uint64_t d_samples_bytes = 0;
   uint32_t* d_order = nullptr;       // persistent mode: hand-out order of the squares (slow-path squares first), cached
@@ -270,6 +273,8 @@ extern "C" int lt_hip_destroy(lt_hip_context* ctx) {
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
   if (ctx->d_queues) (void)hipFree(ctx->d_queues);
   if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+  if (ctx->d_shadowq) (void)hipFree(ctx->d_shadowq);
+  if (ctx->d_shadowCtl) (void)hipFree(ctx->d_shadowCtl);
   if (ctx->d_order) (void)hipFree(ctx->d_order);
   for (auto& up : ctx->user_programs) (void)hipModuleUnload(up.module);
   for (void*& b : ctx->d_gi) if (b) (void)hipFree(b);
@@ -756,7 +761,8 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
   {
     const char* spe = getenv("LT_SHADOW_PACKETS");
     const int timed = ctx->shadow_mode[LT_PROGRAM_ACCUMULATOR];
-    scPrimary.shadowPackets = spe ? (uint32_t)std::max(0, std::min(2, atoi(spe))) : (timed < 0 ? 1u : (uint32_t)timed);
+    scPrimary.shadowPackets = spe ? (uint32_t)std::max(0, std::min(3, atoi(spe))) : (timed < 0 ? 1u : (uint32_t)timed);
+    if (scPrimary.shadowPackets == 3u) scPrimary.shadowPackets = 0u;   // (queued is accumulator's own; where it won, the rays are not packets)
   }
   // A scene of a few hundred triangles rides in LDS for the bounce stages' per-lane walks (Config::kLdsScene): workgroups of
   // eight waves share one copy.  LT_GI_LDS_SCENE=0 turns it off (A/B measurements).
@@ -1074,22 +1080,19 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   sc.mats = (const Material*)ctx->d_mats;
   sc.lights = (const Lights*)ctx->d_lights;
   sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_mats = ctx->n_mats;
-  // Shadow rays as any-hit packets, per lane, or chosen per wavefront (traverse(), lt_device.hpp): which is fastest depends on
-  // the scene (wall: 17.4 ms as packets, 24.3 per lane; soup: the other way round), so each (scene, program, image geometry) is
-  // timed once, on the first launch that can be repeated without changing the result, and the fastest walk kept.
-  // LT_SHADOW_PACKETS=0/1/2 forces one (tests, A/B measurements).
+  // Shadow rays as any-hit packets, per lane, chosen per wavefront (traverse(), lt_device.hpp) or queued for lt_trace_kernel
+  // (accumulator): which is fastest depends on the scene (wall: packets; soup: the queue), so each (scene, program, image geometry,
+  // frames per launch) is timed once, on the first launch that can be repeated without changing the result, and the fastest
+  // walk kept.  LT_SHADOW_PACKETS=0/1/2/3 forces one (tests, A/B measurements).
   const char* spe = getenv("LT_SHADOW_PACKETS");
   const bool hasShadowRays = d->program == LT_PROGRAM_ACCUMULATOR || d->program == LT_PROGRAM_BASIC_LIGHTING;   // (the GI programs' kernels hold the per-lane walk only)
   // (keyed on the image geometry too: how coherent a wavefront's 64 shadow rays are depends on how large its 8x8 pixels are in
   // the scene; shadow_mode[program] keeps the most recent verdict for callers without a geometry of their own: the GI pipeline)
-  const std::vector<uint32_t> shadowKey = {(uint32_t)d->program, d->width, d->height, p.tileW, p.tileH, p.tileFirst, p.tileStride};
-  int shadowMode = 0;
-  if (spe) shadowMode = std::max(0, std::min(2, atoi(spe)));
-  else if (hasShadowRays) {
-    auto it = ctx->shadow_modes.find(shadowKey);
-    shadowMode = it == ctx->shadow_modes.end() ? -1 : it->second;
-  }
-  sc.shadowPackets = shadowMode > 0 ? (uint32_t)shadowMode : 0u;
+  std::vector<uint32_t> shadowKey = {(uint32_t)d->program, d->width, d->height, p.tileW, p.tileH, p.tileFirst, p.tileStride, 0u};   // (+ frames per launch, below)
+  int shadowMode = 0;   // (looked up once the frames per launch are known, below)
+  sc.shadowPackets = 0u;
+  sc.shadowQueue = nullptr;
+  sc.shadowCap = 0u;
   {
     const char* se = getenv("LT_SHADOW_SPREAD");
     const float thr = se ? (float)atof(se) : 0.02f;
@@ -1161,6 +1164,16 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
   const uint32_t chunk = fu.chunk, samplesPerSet = fu.samplesPerSet;
   const uint64_t giPixels = fu.giPixels;
   const bool paddedTiles = d->width % p.tileW != 0 || d->height % p.tileH != 0;
+  {   // (frames per launch in three classes: a launch pays a fixed price for its slowest squares, which the walks share out differently)
+    const uint32_t lf = fused ? std::min(chunk, frames) : 1u;
+    shadowKey[7] = lf == 1u ? 1u : lf < 8u ? 2u : 8u;
+  }
+  if (spe) shadowMode = std::max(0, std::min(3, atoi(spe)));
+  else if (hasShadowRays) {
+    auto it = ctx->shadow_modes.find(shadowKey);
+    shadowMode = it == ctx->shadow_modes.end() ? -1 : it->second;
+  }
+  sc.shadowPackets = shadowMode > 0 ? (uint32_t)shadowMode : 0u;
   ctx->mean_pairs = 0;
   LT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, s));
   uint32_t launches = 0;
@@ -1200,11 +1213,9 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         const hipFunction_t fn = devlibm == 2 ? up.lds : devlibm == 1 ? up.ldsStrict : up.ldsPortable;
         LT_HIP_CHECK(ctx, hipModuleLaunchKernel(fn, grid.x, 1, 1, kBlock, 1, 1, lds, s, args, nullptr));
       } else {
-        // Time the three shadow-ray walks (packets, per lane, chosen per wavefront) once per (scene, program, image geometry), ahead
-        // of a launch whose output they may scribble on (it overwrites what it writes, as every fused launch does): the launch's
-        // FIRST FOUR frames run six times -- the three walks in turn, twice -- and each walk is given the faster of its two runs, so
-        // the first, cache-cold launch of a scene and a one-off hiccup decide nothing; then the launch itself runs once, with the winner.
-        const bool calibrate = shadowMode < 0 && persistent && !stats && ctx->bvh_height <= kLdsStack && fp.accumulateN < 0;
+        // One frame-set of the call with a given shadow-ray walk: the render launch and, when the shadow rays are queued (mode 3:
+        // accumulator, a tree of the backend's own, a launch that overwrites what it writes), lt_trace_kernel over the queue and
+        // the kernel that blacks out the occluded samples.
         auto launch_render = [&](const FrameParams& fpl, dim3 g) {
           switch (d->program) {
             case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
@@ -1215,41 +1226,76 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
             default: launch_program<kCustom>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
           }
         };
+        const bool queueOk = d->program == LT_PROGRAM_ACCUMULATOR && persistent && !stats && ctx->d_rank8 != nullptr && fp.accumulateN < 0 &&
+                             nblocks * nf * kBlock < 0xffffffffull;
+        auto launch_walk = [&](uint32_t mode, const FrameParams& fpl, dim3 g) -> int {
+          sc.shadowPackets = mode;
+          if (mode != 3u) { launch_render(fpl, g); return LT_OK; }
+          const uint64_t slots = nblocks * fpl.fusedFrames * kBlock;
+          if (ctx->shadowq_slots < slots) {
+            if (ctx->d_shadowq) LT_HIP_CHECK(ctx, hipFree(ctx->d_shadowq));
+            ctx->d_shadowq = nullptr;
+            ctx->shadowq_slots = 0;
+            LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_shadowq, slots * 64));
+            ctx->shadowq_slots = slots;
+          }
+          if (!ctx->d_shadowCtl) LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_shadowCtl, 9 * kQueueStride * sizeof(uint32_t)));
+          LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_shadowCtl, 0, 8 * kQueueStride * sizeof(uint32_t), s));
+          LT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_shadowCtl + 8 * kQueueStride), (int)(uint32_t)slots, 1, s));
+          sc.shadowQueue = (float4*)ctx->d_shadowq;
+          sc.shadowCap = (uint32_t)ctx->shadowq_slots;
+          launch_render(fpl, g);
+          TraceParams tp{};
+          tp.o = sc.shadowQueue; tp.d = sc.shadowQueue + sc.shadowCap; tp.m = (const uint4*)(sc.shadowQueue + 2 * (size_t)sc.shadowCap);
+          tp.hit = (uint4*)(sc.shadowQueue + 3 * (size_t)sc.shadowCap);
+          tp.count = ctx->d_shadowCtl + 8 * kQueueStride;
+          tp.next = ctx->d_shadowCtl;
+          const char* re = getenv("LT_TRACE_REFILL");
+          tp.refill = re ? (uint32_t)std::max(1, std::min(64, atoi(re))) : 24u;
+          tp.dead = 1u;
+          hipLaunchKernelGGL((lt_trace_kernel<kGI, true>), dim3(resident), dim3(kBlock), (uint32_t)((kTraceRows + kTraceStage) * kBlock * sizeof(int)), s, sc, tp);
+          hipLaunchKernelGGL(lt_shadow_resolve_kernel, dim3((uint32_t)ctx->cu_count * 8u), dim3(256), 0, s, tp.m, (const uint4*)tp.hit, (uint32_t)slots, out_launch,
+                             fpl.frameStride, fpl.depth);
+          LT_HIP_CHECK(ctx, hipGetLastError());
+          launches += 2;
+          return LT_OK;
+        };
+        if (shadowMode == 3 && !queueOk) shadowMode = spe ? 0 : -1;   // (a forced or remembered mode 3 where it cannot run)
+        // Time the shadow-ray walks (any-hit packets, per lane, chosen per wavefront, queued for lt_trace_kernel) once per (scene,
+        // program, image geometry, frames per launch), ahead of a launch whose output they may scribble on (it overwrites what it
+        // writes, as every fused launch does): the launch as it is -- a verdict on fewer frames is another launch's verdict: a
+        // launch pays a fixed price for its slowest squares, which the walks share out differently -- once per walk after one
+        // untimed run.  The fastest wins, unless the walk an earlier verdict on this scene picked is within 3 % of it: two walks
+        // that close must not take turns from call to call.
+        const bool calibrate = shadowMode < 0 && persistent && !stats && ctx->bvh_height <= kLdsStack && fp.accumulateN < 0;
         if (calibrate) {
           for (hipEvent_t& e : ctx->cal_ev) if (!e) LT_HIP_CHECK(ctx, hipEventCreate(&e));
-          FrameParams f1 = fp;
-          // (enough of the call's frames for about four 4K images' worth of squares: a short launch ends when its slowest squares
-          // do -- the image's centre row and column, whose non-finite rays walk the caller's tree -- whatever the others do, and
-          // an eighth of a frame -- one GPU's share of eight -- timed that way picked the per-lane walk where packets are 30 %
-          // faster)
-          const uint32_t enough = (uint32_t)std::min<uint64_t>(1024u, (4ull * 129600ull + fp.totalSquares - 1) / std::max(1u, fp.totalSquares));
-          f1.fusedFrames = std::min(fp.fusedFrames, std::max(4u, enough));
-          const dim3 g1((uint32_t)std::min<uint64_t>(nblocks, resident));
-          static const uint32_t kOrder[3] = {1u, 0u, 2u};
-          for (int pass = 0; pass < 6; pass++) {
-            sc.shadowPackets = kOrder[pass % 3];
-            if (pass > 0) LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
-            LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass], s));
-            launch_render(f1, g1);
-            LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass + 1], s));
+          const uint32_t kOrder[4] = {1u, 0u, 2u, 3u};
+          const int candidates = queueOk ? 4 : 3;
+          for (int pass = -1; pass < candidates; pass++) {
+            if (pass >= 0) LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass], s));
+            const int wrc = launch_walk(kOrder[pass < 0 ? 0 : pass], fp, grid);
+            if (wrc) return wrc;
+            if (pass >= 0) LT_HIP_CHECK(ctx, hipEventRecord(ctx->cal_ev[2 * pass + 1], s));
+            LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
           }
-          float t[6];
-          LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->cal_ev[11]));
-          for (int k = 0; k < 6; k++) LT_HIP_CHECK(ctx, hipEventElapsedTime(&t[k], ctx->cal_ev[2 * k], ctx->cal_ev[2 * k + 1]));
-          const float packets = std::min(t[0], t[3]), perLane = std::min(t[1], t[4]), perWave = std::min(t[2], t[5]);
+          float t[4] = {0, 0, 0, 0};
+          LT_HIP_CHECK(ctx, hipEventSynchronize(ctx->cal_ev[2 * candidates - 1]));
+          for (int k = 0; k < candidates; k++) LT_HIP_CHECK(ctx, hipEventElapsedTime(&t[k], ctx->cal_ev[2 * k], ctx->cal_ev[2 * k + 1]));
           if (getenv("LT_DEBUG_CALIBRATION"))
-            fprintf(stderr, "shadow-walk timing (ms): packets %.3f %.3f, per lane %.3f %.3f, per wavefront %.3f %.3f\n", t[0], t[3], t[1], t[4], t[2], t[5]);
-          float best = perLane;                                  // (ties keep the simpler walk: per lane, then packets)
-          shadowMode = 0;
-          if (packets < 0.99f * best) { shadowMode = 1; best = packets; }
-          if (perWave < 0.99f * best) shadowMode = 2;
+            fprintf(stderr, "shadow-walk timing (ms, %u frames): packets %.3f, per lane %.3f, per wavefront %.3f, queued %.3f\n", fp.fusedFrames, t[0], t[1], t[2], t[3]);
+          int best = 0;
+          for (int k = 1; k < candidates; k++) if (t[k] < t[best]) best = k;
+          shadowMode = (int)kOrder[best];
+          const int earlier = ctx->shadow_mode[d->program];
+          for (int k = 0; k < candidates; k++)
+            if ((int)kOrder[k] == earlier && t[k] <= 1.03f * t[best]) shadowMode = earlier;
           ctx->shadow_modes[shadowKey] = shadowMode;
           ctx->shadow_mode[d->program] = shadowMode;
-          sc.shadowPackets = (uint32_t)shadowMode;
-          launches += 6;
-          LT_HIP_CHECK(ctx, hipMemsetAsync(queues, 0, 8 * kQueueStride * sizeof(uint32_t), s));
+          launches += (uint32_t)candidates + 1u;
         }
-        launch_render(fp, grid);
+        const int wrc = launch_walk((uint32_t)std::max(0, shadowMode), fp, grid);
+        if (wrc) return wrc;
       }
       LT_HIP_CHECK(ctx, hipGetLastError());
       launches++;

@@ -42,6 +42,7 @@ constexpr int kOwnDeep = 48;       // ... and the entries beyond them, in privat
 constexpr int kTraceRows = 10;     // lt_trace_kernel: LDS rows of its lanes' stacks (kOwnRows + kOwnDeep - kTraceRows entries in private memory) ...
 constexpr int kTraceStage = 10;    // ... and of its staged rays (origin 3, direction 4, ignored primitive, tmax, index): 20 rows = 5 KB, 32 waves per CU
 constexpr float kFltMax = 3.402823466e+38f;
+constexpr uint32_t kDeadSlot = 0xffffffffu;   // first word of the third array of a direct-mapped ray queue's slot that holds no ray
 
 enum Program { kBasic = 0, kBasicLighting = 1, kAccumulator = 2, kGI = 3, kGI25 = 4, kCustom = 5,
                kGIPrimary = 6,   // the global-illumination programs' camera-ray stage (lt_gi_primary_kernel): kGI's arithmetic; its shadow
@@ -90,8 +91,16 @@ struct SceneDev {
   const Material* mats;
   const Lights* lights;
   uint32_t n_nodes, n_prims, n_mats;
-  uint32_t shadowPackets;   // shadow rays of the non-counting kernels: 0 per lane, 1 as any-hit packets, 2 chosen per wavefront (shadowSpread);
-                            // the host times the three on a scene's first frame (lt_capi.hip)
+  uint32_t shadowPackets;   // shadow rays of the non-counting kernels: 0 per lane, 1 as any-hit packets, 2 chosen per wavefront (shadowSpread),
+                            // 3 (accumulator) not walked by the render kernel at all but QUEUED for lt_trace_kernel (lt_kernel.hpp),
+                            // whose lanes take a new ray when theirs is done: the kernel stores the colour an unoccluded sample
+                            // has, lt_shadow_resolve_kernel blacks out the occluded ones;
+                            // the host times the four on a scene's first frame (lt_capi.hip)
+  // mode 3: the direct-mapped shadow queue, capacity shadowCap slots: origin + tmax, direction, (pixel, ignored primitive, frame, -)
+  // at shadowQueue, + shadowCap, + 2 shadowCap; slot = (position of the square in the hand-out order * frames + frame) * 64 + lane;
+  // a slot without a ray carries kDeadSlot as its pixel
+  float4* shadowQueue;
+  uint32_t shadowCap;
   // A scene of a few hundred triangles (the Cornell box: 83 nodes + 42 triangles = 4.7 KB) lives in LDS for the per-lane walks of
   // the kernels instantiated with Config::kLdsScene: byte offsets of the workgroup's copies of `nodes` and `tris` in its LDS
   // (filled by the kernel itself, lt_kernel.hpp).  An incoherent per-lane walk is 64 distinct 32-byte fetches per visited node,
@@ -1117,9 +1126,11 @@ __device__ inline V3 shade_custom(const SceneDev& sc, const Ray& ray, Stack<CFG:
 }
 
 // acc.cl:219-282 / basic_lighting.cl:220-277
+// (qslot / qpixel / qframe: where a queued shadow ray goes and which stored colour it decides -- SceneDev::shadowPackets == 3;
+// queued: it went)
 template <int PROGRAM, class CFG>
 __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, float fx, float fy, uint32_t s,
-                                    Stack<CFG::kDeep>& st, Counters& c) {
+                                    Stack<CFG::kDeep>& st, Counters& c, uint32_t qslot, uint32_t qpixel, uint32_t qframe, bool& queued) {
   V3 out{0.0f, 0.0f, 0.0f};
   Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
   traverse_camera<PROGRAM, CFG::kDeep, CFG::kStats>(sc, cameraRay, pl, st, c);
@@ -1130,7 +1141,19 @@ __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, fl
     const float* pr = prim_ptr(sc, pl.prim);
     V4 position, normal;
     float ndotl;
-    if (direct_light<PROGRAM, CFG>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u),
+    if (PROGRAM == kAccumulator && !CFG::kStats && sc.shadowPackets == 3u) {
+      // the shadow ray goes into the queue (lt_trace_kernel walks it); the colour is the unoccluded sample's until
+      // lt_shadow_resolve_kernel has looked at the ray's fate
+      V4 toLight;
+      float tmax;
+      light_sample<CFG>(sc, pr, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u), 0.0f, position, normal, toLight, tmax, ndotl);
+      sc.shadowQueue[qslot] = make_float4(position.x, position.y, position.z, tmax);
+      sc.shadowQueue[(size_t)sc.shadowCap + qslot] = make_float4(toLight.x, toLight.y, toLight.z, toLight.w);
+      ((uint4*)sc.shadowQueue)[2 * (size_t)sc.shadowCap + qslot] = make_uint4(qpixel, (uint32_t)pl.prim, qframe, 0u);
+      queued = true;
+      const Material* m = sc.mats + prim_material(pr);
+      out = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
+    } else if (direct_light<PROGRAM, CFG>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u),
                                            0.0f, position, normal, ndotl, st, c)) {
       const Material* m = sc.mats + prim_material(pr);
       out = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
@@ -1282,7 +1305,7 @@ __device__ V3 user_shade(const SceneDev& sc, const Ray& cameraRay, float filmX, 
 // (acc.cl:314-318, basic.cl:338-342, basic_lighting.cl:309-321, resources gi :408-420).
 template <int PROGRAM, class CFG>
 __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, uint32_t frameCount, int x, int y, Stack<CFG::kDeep>& st,
-                                 Counters& c) {
+                                 Counters& c, uint32_t qslot, uint32_t qpixel, uint32_t qframe, bool& queued) {
   float fx, fy;
   const Ray ray = camera_ray<CFG::kDevLibm>(fp, x, y, fx, fy);
   V3 color;
@@ -1295,14 +1318,14 @@ __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, uint
     color = user_shade<CFG>(sc, ray, fx, fy, frameCount, st, c);
 #endif
   } else if (PROGRAM == kAccumulator) {
-    color = shade_lighting<kAccumulator, CFG>(sc, ray, fx, fy, frameCount, st, c);
+    color = shade_lighting<kAccumulator, CFG>(sc, ray, fx, fy, frameCount, st, c, qslot, qpixel, qframe, queued);
   } else if (PROGRAM == kGI) {
     color = shade_gi<CFG>(sc, ray, fx, fy, frameCount, fp.giMaxDepth, st, c);
   } else {
     const uint32_t base = frameCount * 32u;
     for (int k = 0; k < 25; k++) {
       const V3 cn = (PROGRAM == kBasicLighting)
-                        ? shade_lighting<kBasicLighting, CFG>(sc, ray, fx, fy, base + (uint32_t)k, st, c)
+                        ? shade_lighting<kBasicLighting, CFG>(sc, ray, fx, fy, base + (uint32_t)k, st, c, 0u, 0u, 0u, queued)
                         : shade_gi<CFG>(sc, ray, fx, fy, base + (uint32_t)k, fp.giMaxDepth, st, c);
       if (k == 0) {
         color = cn;

@@ -17,9 +17,10 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 }
 
 // One 8x8 pixel square (logical index b, already XCD-ordered) by one wavefront.
+// (pos: the square's position in the hand-out order -- what a queued shadow ray's slot is made of, SceneDev::shadowPackets == 3)
 template <int PROGRAM, class CFG>
 __device__ __forceinline__ void render_square(const SceneDev& sc, const FrameParams& fp, float* __restrict__ out, uint32_t b,
-                                              uint32_t frame, Stack<CFG::kDeep>& st, Counters& c) {
+                                              uint32_t frame, Stack<CFG::kDeep>& st, Counters& c, uint32_t pos) {
   constexpr bool STATS = CFG::kStats;
   const uint32_t k = b / fp.blocksPerTile, sb = b % fp.blocksPerTile;
   const uint32_t sbx = sb % fp.blocksPerTileX, sby = sb / fp.blocksPerTileX;
@@ -30,9 +31,13 @@ __device__ __forceinline__ void render_square(const SceneDev& sc, const FramePar
   const uint32_t ly = sby * 8u + (lane >> 3);
   const uint32_t x = tx * fp.tileW + lx, y = ty * fp.tileH + ly;
   const bool valid = k < fp.tilesInCall && lx < fp.tileW && ly < fp.tileH && x < fp.width && y < fp.height;
+  const bool queueing = PROGRAM == kAccumulator && !STATS && sc.shadowPackets == 3u;
+  const uint32_t qslot = (pos * fp.fusedFrames + frame) * (uint32_t)kBlock + lane;
+  bool queued = false;
   if (valid) {
     Counters pc{};   // this pixel's own counters (diagnostic output), folded into the lane's totals below
-    const V3 color = shade_pixel<PROGRAM, CFG>(sc, fp, fp.frameCount + frame, (int)x, (int)y, st, STATS ? pc : c);
+    const uint32_t pixel = (k * fp.tileH + ly) * fp.tileW + lx;
+    const V3 color = shade_pixel<PROGRAM, CFG>(sc, fp, fp.frameCount + frame, (int)x, (int)y, st, STATS ? pc : c, qslot, pixel, frame, queued);
     float* o = out + (size_t)frame * fp.frameStride + (((size_t)k * fp.tileH + ly) * fp.tileW + lx) * fp.depth;
     if (STATS && fp.pixelCounters) {
       o[0] = (float)pc.rays; o[1] = (float)pc.shadow; o[2] = (float)pc.nodes; o[3] = (float)pc.tris;
@@ -51,6 +56,7 @@ __device__ __forceinline__ void render_square(const SceneDev& sc, const FramePar
 #endif
     }
   }
+  if (queueing && !queued) ((uint4*)sc.shadowQueue)[2 * (size_t)sc.shadowCap + qslot].x = kDeadSlot;   // (every slot of the square says what it holds)
 }
 
 // Registers: the traversal wants every wave slot (8 per SIMD = 64 VGPRs); the single-bounce programs fit that with a few
@@ -90,9 +96,10 @@ __device__ __forceinline__ void render_kernel_body(const SceneDev& sc, const Fra
   uint32_t sweep = 0;
   bool done = false;
   while (!done) {
-    uint32_t b, frame = 0;
+    uint32_t b, frame = 0, pos = 0;
     if (!fp.persistent) {
       b = xcd_remap(blockIdx.x, gridDim.x);
+      pos = b;
       done = true;
     } else {
       const uint32_t xcd = (home + sweep) & 7u;
@@ -120,9 +127,10 @@ __device__ __forceinline__ void render_kernel_body(const SceneDev& sc, const Fra
         }
       }
       b = start + t;
+      pos = b;
       if (fp.order) b = (uint32_t)__builtin_amdgcn_readfirstlane((int)fp.order[b]);
     }
-    render_square<PROGRAM, CFG>(sc, fp, out, b, frame, st, c);
+    render_square<PROGRAM, CFG>(sc, fp, out, b, frame, st, c, pos);
   }
   if (STATS) {
     atomicAdd(&stats[0], (unsigned long long)c.rays);
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(PROGRAM)) void lt_render_ker
 // re-traces the identical ray each time: same hit, same term).  Used when work is not being counted; the counting variants
 // run the one-lane-per-pixel kernel, which re-traces like the reference does.
 struct GiQueue { float4* o; float4* d; float4* n; uint4* m; };
-constexpr uint32_t kDeadPath = 0xffffffffu;   // m.x of a slot of a direct-mapped queue that holds no path
+constexpr uint32_t kDeadPath = kDeadSlot;    // m.x of a slot of a direct-mapped queue that holds no path
 
 struct GiParams {
   GiQueue q[2];            // ping-pong: stage d reads q[d & 1], writes q[(d + 1) & 1]
@@ -642,6 +650,19 @@ __global__ __launch_bounds__(kBlock, 8) void lt_trace_kernel(SceneDev sc, TraceP
         active = false;
       }
     }
+  }
+}
+
+// accumulator's shadow rays walked by lt_trace_kernel (SceneDev::shadowPackets == 3): a sample whose ray met an occluder is
+// black (acc.cl:276-279: the colour is only assigned when the shadow payload's hitType is 0)
+__global__ __launch_bounds__(256) void lt_shadow_resolve_kernel(const uint4* __restrict__ m, const uint4* __restrict__ hit, uint32_t slots, float* __restrict__ out,
+                                                                unsigned long long frameStride, uint32_t depth) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += stride) {
+    const uint4 mm = m[i];
+    if (mm.x == kDeadSlot || hit[i].y == 0u) continue;
+    float* o = out + (size_t)mm.z * frameStride + (size_t)mm.x * depth;
+    o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
   }
 }
 

@@ -189,7 +189,7 @@ def test_sah_built_scenes_match_the_oracle_bit_for_bit(renderer, monkeypatch, na
     W, H = 160, 96
     cam = sc.camera_bytes(0.0, 2.5, -50.0, 0.02 if name == "soup" else 0.0, 0.0, 0.0, 3)
     want, st = po.render(s, cam, W, H, po.ACCUMULATOR, threads=8, want_stats=True)
-    for packets in ("0", "1"):
+    for packets in ("0", "1", "3"):
         monkeypatch.setenv("LT_SHADOW_PACKETS", packets)
         got = np.empty((H, W, 3), dtype=np.float32)
         renderer.render(RenderPropertiesHIP(PATHS["accumulator"], (W, H, 3), got, s, pCamera=cam))

@@ -109,7 +109,7 @@ def test_bench_partition_of_the_16_sample_frame_reassembles_exactly(renderer, wa
         d = make_desc(C.PROGRAM_ACCUMULATOR, W, H, 3, wall.camera, frame_first=1, frame_count=16, accumulate=True, accumulate_base=0,
                       tile=plan.desc_tile(r))
         renderer.render_device(d, stack[r].data_ptr(), plan.floats_per_rank * 4, stream)
-        assert renderer.stats()["kernel_launches"] in (1, 7)      # (7: the first call of a geometry times the three shadow-ray walks on its first frame, twice each)
+        assert renderer.stats()["kernel_launches"] >= 1           # (more than the call's own when it is the first of its geometry: the shadow-ray walks are timed)
     image = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0")
     renderer.untile(stack.data_ptr(), plan.floats_per_rank, 8, W, H, 3, plan.tile_w, plan.tile_h, image.data_ptr(), stream)
     torch.cuda.synchronize()
@@ -123,7 +123,7 @@ def test_shadow_ray_walks_agree_on_the_full_frame(renderer, wall, monkeypatch):
         cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, 3)
         frames = {}
         monkeypatch.setenv("LT_SHADOW_SPREAD", "0.004")     # (the wall's bundles sit around this spread: both walks occur)
-        for mode in ("0", "1", "2"):
+        for mode in ("0", "1", "2", "3"):
             monkeypatch.setenv("LT_SHADOW_PACKETS", mode)
             out = np.empty((H, W, 3), dtype=np.float32)
             renderer.render(RenderPropertiesHIP(ACC, (W, H, 3), out, wall, pCamera=cam, frameFirst=3, frameCount=2, accumulate=True))
@@ -164,7 +164,7 @@ def test_whole_4k_frame_matches_reference_accumulator_kernel(renderer, wall, mon
     cam = sc.camera_bytes(0.0, 2.5, -50.0, yaw, 0.0, 0.0, 2)
     ref = ref_gpu.render(wall, cam, W, H, "accumulator", build)
     assert ref.shape == (H, W, 3) and ref.sum() > 0
-    for packets in ("1", "0"):
+    for packets in ("1", "0", "3"):
         monkeypatch.setenv("LT_SHADOW_PACKETS", packets)
         got = np.empty((H, W, 3), dtype=np.float32)
         renderer.render(DefaultFlavourProps(ACC, (W, H, 3), got, wall, pCamera=cam, strictMath=(build == "strict")))

@@ -81,7 +81,7 @@ def test_callers_splits_and_own_splits_give_the_same_frame(monkeypatch, name):
     frames = {}
     for retree in ("1", "0"):
         r = fresh(monkeypatch, LT_RETREE=retree)
-        for packets in ("0", "1", "2"):
+        for packets in ("0", "1", "2", "3"):
             monkeypatch.setenv("LT_SHADOW_PACKETS", packets)
             frames[retree, packets] = render(r, s, "accumulator", W, H, cam)
             assert r.stats()["own_tree_height"] > 0

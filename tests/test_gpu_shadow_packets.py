@@ -37,7 +37,7 @@ def scenes():
 
 
 @pytest.mark.parametrize("name,scene", list(scenes()), ids=lambda v: v if isinstance(v, str) else "")
-@pytest.mark.parametrize("forced", ["0", "1", "2"], ids=["per-lane", "packets", "per-wavefront"])
+@pytest.mark.parametrize("forced", ["0", "1", "2", "3"], ids=["per-lane", "packets", "per-wavefront", "queued"])
 def test_both_walks_match_the_oracle(renderer, monkeypatch, forced, name, scene):
     monkeypatch.setenv("LT_SHADOW_PACKETS", forced)
     if forced == "2":
@@ -50,7 +50,8 @@ def test_both_walks_match_the_oracle(renderer, monkeypatch, forced, name, scene)
             monkeypatch.setenv("LT_GI_MEGAKERNEL", gi_path)
             out = np.full((H, W, 3), np.nan, dtype=np.float32)
             renderer.render(RenderPropertiesHIP(PATHS[prog], (W, H, 3), out, scene, pCamera=cam, **kw))
-            assert renderer.stats()["shadow_packets"] == int(forced)
+            # (queued shadow rays are accumulator's: the other programs' kernels walk them per lane when told to queue)
+            assert renderer.stats()["shadow_packets"] == (int(forced) if forced != "3" or prog == "accumulator" else 0)
             want = po.render(scene, cam, W, H, po.PROGRAMS[prog], kw.get("kernelMode", 0), gi_max_depth=kw.get("giMaxDepth", 16))
             assert np.array_equal(out, want), (name, prog, W, H, gi_path)
 
@@ -68,31 +69,36 @@ def test_the_walk_is_timed_once_per_scene_program_and_image_geometry(monkeypatch
         r.render(RenderPropertiesHIP(path, (W, H, 3), out, scene, pCamera=sc.camera_with_frame(scene.camera, 1), **kw))
         return out, r.stats()
 
+    def own(mode):                   # launches of a call that times nothing: the render launch (+ trace and resolve of queued shadow rays)
+        return 3 if mode == 3 else 1
+
     out, st = once(PATHS["accumulator"])
-    # the launch's first frame runs six times (packets, per lane, chosen per wavefront, twice: each walk keeps its faster run),
-    # then the launch itself with the winner
-    assert st["kernel_launches"] == 7 and st["shadow_packets"] in (0, 1, 2)
+    # the launch runs once untimed and once per walk (packets, per lane, chosen per wavefront, queued), then once more with the winner
+    assert st["kernel_launches"] == 5 + 2 + own(st["shadow_packets"]) and st["shadow_packets"] in (0, 1, 2, 3)
     assert np.array_equal(out, want)
     chosen = st["shadow_packets"]
     out, st = once(PATHS["accumulator"])
-    assert st["kernel_launches"] == 1 and st["shadow_packets"] == chosen
+    assert st["kernel_launches"] == own(chosen) and st["shadow_packets"] == chosen
     assert np.array_equal(out, want)
+    out, st = once(PATHS["accumulator"], frameFirst=1, frameCount=3, accumulate=True)    # another number of frames per launch: timed again
+    assert st["kernel_launches"] == 5 + 2 + own(st["shadow_packets"]) + 1
+    fused = st["shadow_packets"]
     out, st = once(PATHS["accumulator"], frameFirst=1, frameCount=3, accumulate=True)
-    assert st["kernel_launches"] == 1 and st["shadow_packets"] == chosen          # known: the fused launch is not repeated
+    assert st["kernel_launches"] == own(fused) + 1 and st["shadow_packets"] == fused      # known: nothing is repeated (+ the fold)
     W, H = 200, 120                                                               # another image geometry: timed again, once
     want = po.render(scene, sc.camera_with_frame(scene.camera, 1), W, H, po.ACCUMULATOR)
     out, st = once(PATHS["accumulator"])
-    assert st["kernel_launches"] == 7 and np.array_equal(out, want)
+    assert st["kernel_launches"] == 5 + 2 + own(st["shadow_packets"]) and np.array_equal(out, want)
     out, st = once(PATHS["accumulator"])
-    assert st["kernel_launches"] == 1 and np.array_equal(out, want)
+    assert st["kernel_launches"] == own(st["shadow_packets"]) and np.array_equal(out, want)
     out, st = once("resources/kernels/opencl/basic.cl")
     assert st["kernel_launches"] == 1 and st["shadow_packets"] == 0               # no shadow rays: nothing to time
     out, st = once(PATHS["basic_lighting"])
-    assert st["kernel_launches"] == 7                                             # its own decision
+    assert st["kernel_launches"] == 4 + 1                                         # its own decision (its shadow rays cannot be queued: three walks)
     r.set_scene(synth.heightfield_wall(32).validate())                            # a new scene forgets the decisions
     scene = synth.heightfield_wall(32).validate()
     out, st = once(PATHS["accumulator"], frameFirst=1, frameCount=4, accumulate=True)
-    assert st["kernel_launches"] == 7                                             # timed on the first frame of the fused launch
+    assert st["kernel_launches"] == 5 + 2 + own(st["shadow_packets"]) + 1         # timed on the fused launch itself (+ the fold)
     out2, st = once(PATHS["accumulator"], frameFirst=1, frameCount=4, accumulate=True)
-    assert st["kernel_launches"] == 1 and np.array_equal(out, out2)
+    assert st["kernel_launches"] == own(st["shadow_packets"]) + 1 and np.array_equal(out, out2)
     r.close()
