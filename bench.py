@@ -119,6 +119,7 @@ def parse():
                     "the timed region.  0 (default) = 1 on one GPU, 2 on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-soup", action="store_true", help="skip the second figure (config 4's incoherent triangle-soup variant)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end figures (frame into a caller's host buffer, through the plugin's render())")
     return ap.parse_args()
 
 
@@ -348,6 +349,8 @@ def main():
                                  "lt_render_kernel<%s>" % args.program if launches_per_step <= args.spp else "wavefront GI pipeline (all its stage kernels)",
                                  launch_ms, launches_per_step, args.spp, my_alg_bytes_per_launch, world == 1),
         }
+        if world == 1 and not args.no_e2e:
+            out["config"].update(e2e_figures(args, scene, r))
         if world == 1 and args.scene == "wall" and not args.no_soup:
             # the same walks over the caller's own (median-split) hierarchy ...
             out["config"].update(callers_splits_figure(args, scene, program, dev, stream, rays_total))
@@ -362,6 +365,42 @@ def main():
     for sl in slots[1:]:
         sl.r.close()
     r.close()
+
+
+def e2e_figures(args, scene, r):
+    """The same frame END TO END, the way the reference's contract has it -- on return the caller's HOST buffer is complete
+    (src/opencl/renderer_opencl.cpp:146-149) -- a few whole steps each, after the timed region:
+      e2e_frame_ms_host_buffer : lt_hip_render: the step + the 99.5 MB read-back (pinned pieces, copied on by host threads)
+      e2e_frame_ms_plugin      : RendererHIP.render() with the default scene-change contract, i.e. the caller hands over its scene
+                                 with every frame as the reference's callers do (renderer_opencl.cpp:107-120): lt_hip_render_scene
+                                 hashes all of it while the frame renders
+      scene_hash_ms            : that hash alone (lt_hip_set_scene of the unchanged scene), for scale: it is not added to anything"""
+    import numpy as np
+    from lens_trace_amd.renderer import RenderPropertiesHIP
+    W, H = args.width, args.height
+    out = np.empty((H, W, 3), dtype=np.float32)
+    path = args.program if "/" in args.program or "." in args.program else args.program + ".cl"
+    if args.program == "global_illumination":
+        path = "examples/global_illumination/resources/kernels/global_illumination.cl"
+    steps = max(2, min(args.steps, 5))
+
+    def timed(props):
+        r.render(props)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.render(props)
+        return (time.perf_counter() - t0) / steps * 1e3
+    base = dict(kernelFilePath=path, imageDimensions=(W, H, 3), pOutputBuffer=out, pAccelerationStructureExplicit=scene, pCamera=scene.camera,
+                frameFirst=1, frameCount=args.spp, accumulate=True)
+    r.set_scene(scene)
+    versioned = timed(RenderPropertiesHIP(sceneVersion=1, **base))      # the scene is known: lt_hip_render
+    plugin = timed(RenderPropertiesHIP(sceneVersion=0, **base))         # the scene comes with the frame: lt_hip_render_scene
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.set_scene(scene)
+    hash_ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"e2e_frame_ms_host_buffer": round(versioned, 3), "e2e_frame_ms_plugin": round(plugin, 3), "scene_hash_ms": round(hash_ms, 3),
+            "e2e_readback_bytes": int(out.nbytes), "e2e_scene_bytes": int(scene.nodes.nbytes + scene.prims.nbytes + scene.materials.nbytes + scene.lights.nbytes)}
 
 
 def callers_splits_figure(args, scene, program, dev, stream, rays_per_step):

@@ -16,6 +16,7 @@
  *   5 x clCreateBuffer + clEnqueueWriteBuffer  :107-120                     lt_hip_set_scene
  *     (node / ordered-primitive / material / light-container buffers;
  *      uploaded once and cached instead of on every render() call)
+ *   the two together, per render() call                                    lt_hip_render_scene
  *   camera buffer upload + kernel args + NDRange launches + wait +          lt_hip_render
  *     blocking read-back into pOutputBuffer    :119-149                     (lt_hip_render_device keeps
  *                                                                            the pixels in HBM)
@@ -198,6 +199,14 @@ int lt_hip_output_floats(const lt_hip_render_desc* desc, uint64_t* out_floats);
 
 /* Reference semantics: synchronous, fills caller-owned HOST memory (pOutputBuffer). */
 int lt_hip_render(lt_hip_context* ctx, const lt_hip_render_desc* desc, float* out_host, uint64_t out_bytes);
+
+/* lt_hip_set_scene followed by lt_hip_render, as one call -- what a plugin's render() does with a caller that hands over its
+ * scene every time (renderer_opencl.cpp:107-120).  Same results and same statuses as the two calls; when the four buffers have
+ * the resident scene's sizes the frame is rendered while the host hashes them, and rendered again only if they turn out to have
+ * changed -- so that an unchanged scene costs no hashing time on top of the frame. */
+int lt_hip_render_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims, uint64_t prim_bytes,
+                        const void* materials, uint64_t material_bytes, const void* lights, uint64_t light_bytes,
+                        const lt_hip_render_desc* desc, float* out_host, uint64_t out_bytes);
 
 /* Same, but the pixels stay in HBM: out_device is device memory of the context's GPU, the work is enqueued
  * on hip_stream (a hipStream_t, NULL = default stream) and NOT waited for. */

@@ -23,7 +23,7 @@ RENDER_FLAG_STRICT_MATH = 16
 # every symbol include/lenstrace_hip.h declares
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",
            "lt_hip_resolve_program",
-           "lt_hip_set_scene", "lt_hip_output_floats", "lt_hip_render", "lt_hip_render_device", "lt_hip_untile",
+           "lt_hip_set_scene", "lt_hip_output_floats", "lt_hip_render", "lt_hip_render_scene", "lt_hip_render_device", "lt_hip_untile",
            "lt_hip_synchronize", "lt_hip_get_stats", "lt_hip_own_hierarchy", "lt_hip_own_wide"]
 
 
@@ -88,6 +88,8 @@ def load():
     L.lt_hip_set_scene.argtypes = [vp, vp, u64, vp, u64, vp, u64, vp, u64]
     L.lt_hip_output_floats.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(u64)]
     L.lt_hip_render.argtypes = [vp, ctypes.POINTER(RenderDesc), vp, u64]
+    if hasattr(L, "lt_hip_render_scene"):
+        L.lt_hip_render_scene.argtypes = [vp, vp, u64, vp, u64, vp, u64, vp, u64, ctypes.POINTER(RenderDesc), vp, u64]
     L.lt_hip_render_device.argtypes = [vp, ctypes.POINTER(RenderDesc), vp, u64, vp]
     L.lt_hip_untile.argtypes = [vp, vp, u64, u32, u32, u32, u32, u32, u32, vp, vp]
     L.lt_hip_synchronize.argtypes = [vp, vp]

@@ -8,8 +8,13 @@
 
 #include <dlfcn.h>
 
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <exception>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -175,6 +180,9 @@ struct lt_hip_context {
   uint32_t scene_uploads = 0, scene_reused = 0;
   float* d_out = nullptr;            // staging output for lt_hip_render
   uint64_t d_out_bytes = 0;
+  void* h_out = nullptr;             // ... and its pinned host twin: the read-back lands here at the link's rate, piece by piece
+  uint64_t h_out_bytes = 0;          //     (a caller's pageable buffer would be read back through the runtime's small bounce buffers)
+  hipEvent_t out_ev[8] = {};         // one event per piece
   unsigned long long* d_stats = nullptr;
   uint32_t* d_queues = nullptr;      // persistent mode: 8 per-XCD work counters per launch of a call
   uint32_t queue_frames = 0;
@@ -270,6 +278,8 @@ extern "C" int lt_hip_destroy(lt_hip_context* ctx) {
   (void)hipDeviceSynchronize();
   free_scene(ctx);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
+  if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+  for (hipEvent_t e : ctx->out_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
   if (ctx->d_queues) (void)hipFree(ctx->d_queues);
   if (ctx->d_samples) (void)hipFree(ctx->d_samples);
@@ -449,13 +459,23 @@ static int validate_scene(const uint8_t* nodes, uint32_t n_nodes, const uint8_t*
   return height;
 }
 
-// 64-bit content hash of a host buffer, four independent multiply-rotate lanes over 32-byte blocks (memory-bound: the four
-// scene buffers of the 1 M-triangle scene, 140 MB, take ~15-20 ms).  Used to tell "the same scene again" from "a buffer was
-// edited in place" without an upload.
-static uint64_t hash_bytes(const void* data, uint64_t n, uint64_t seed) {
+// Host threads for the memory-bound host passes of lt_hip_set_scene (content hash): what the process may run on
+// (sched_getaffinity: a container's CPU share, not the machine's core count), at most 32.
+static int host_threads() {
+  cpu_set_t set;
+  int n = 1;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (const char* e = getenv("LT_HOST_THREADS")) n = atoi(e);
+  return std::max(1, std::min(32, n));
+}
+
+// 64-bit content hash of a host buffer: four independent multiply-rotate lanes over 32-byte blocks, per 4 MiB piece; the pieces'
+// hashes are folded in order, so the value does not depend on how many threads computed them (one pass over host memory at the
+// memory system's rate: the four scene buffers of the 1 M-triangle scene, 140 MB, take a few milliseconds on the GPU box's
+// host; bench.py's e2e figures measure it).  Used to tell "the same scene again" from "a buffer was edited in place" without an upload.
+static uint64_t hash_piece(const uint8_t* b, uint64_t n, uint64_t seed) {
   constexpr uint64_t K = 0x9E3779B97F4A7C15ull;
   uint64_t h[4] = {seed ^ K, seed + 0xC2B2AE3D27D4EB4Full, seed ^ 0x165667B19E3779F9ull, seed + 0x27D4EB2F165667C5ull};
-  const uint8_t* b = (const uint8_t*)data;
   auto block = [&](const uint8_t* q) {
     uint64_t w[4];
     memcpy(w, q, 32);
@@ -475,6 +495,35 @@ static uint64_t hash_bytes(const void* data, uint64_t n, uint64_t seed) {
   for (int k = 0; k < 4; k++) {
     r = (r ^ h[k]) * K;
     r ^= r >> 32;
+  }
+  return r;
+}
+
+// The four scene buffers as one list of pieces, hashed by up to host_threads() threads (fewer when threads cannot be had: the
+// pieces left are hashed by this one).
+static uint64_t hash_scene(const void* const bufs[4], const uint64_t sizes[4]) {
+  constexpr uint64_t kPiece = 4ull << 20;
+  struct Piece { const uint8_t* p; uint64_t n; };
+  std::vector<Piece> pieces;
+  for (int k = 0; k < 4; k++)
+    for (uint64_t off = 0; off < sizes[k]; off += kPiece) pieces.push_back({(const uint8_t*)bufs[k] + off, std::min(kPiece, sizes[k] - off)});
+  std::vector<uint64_t> hashes(pieces.size());
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for (size_t i; (i = next.fetch_add(1)) < pieces.size();) hashes[i] = hash_piece(pieces[i].p, pieces[i].n, (uint64_t)i);
+  };
+  std::vector<std::thread> pool;
+  const int threads = (int)std::min<size_t>((size_t)host_threads(), pieces.size());
+  try {
+    for (int t = 1; t < threads; t++) pool.emplace_back(work);
+  } catch (...) {   // (no more threads to be had: whoever exists does the work)
+  }
+  work();
+  for (std::thread& th : pool) th.join();
+  uint64_t r = 0x243F6A8885A308D3ull;
+  for (uint64_t h : hashes) {
+    r = (r ^ h) * 0x9E3779B97F4A7C15ull;
+    r ^= r >> 29;
   }
   return r;
 }
@@ -533,9 +582,21 @@ extern "C" int lt_hip_own_wide(const void* own_nodes, uint64_t node_bytes, uint3
   return ok ? height : -1;
 }
 
+static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims, uint64_t prim_bytes, const void* materials,
+                          uint64_t material_bytes, const void* lights, uint64_t light_bytes, const uint64_t* known_hash);
+
 extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims,
                                 uint64_t prim_bytes, const void* materials, uint64_t material_bytes, const void* lights,
                                 uint64_t light_bytes) {
+  try {
+    return set_scene_impl(ctx, nodes, node_bytes, prims, prim_bytes, materials, material_bytes, lights, light_bytes, nullptr);
+  } catch (const std::exception& e) {   // (std::bad_alloc, std::system_error of a thread: nothing may cross the C ABI)
+    return fail(ctx, LT_ERR_HIP, std::string("lt_hip_set_scene: ") + e.what());
+  }
+}
+
+static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims, uint64_t prim_bytes, const void* materials,
+                          uint64_t material_bytes, const void* lights, uint64_t light_bytes, const uint64_t* known_hash) {
   if (!ctx) return LT_ERR_INVALID_ARGUMENT;
   if (!nodes || !prims || !materials || !lights) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "NULL scene buffer");
   if (node_bytes == 0 || node_bytes % 32 || prim_bytes == 0 || prim_bytes % 76 || material_bytes == 0 || material_bytes % 32 ||
@@ -547,11 +608,8 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
   // caller hands over the same content again: sizes and a hash of EVERY byte (so an in-place edit of any vertex, node or
   // material is honoured).  LT_SCENE_ALWAYS_UPLOAD=1 turns the shortcut off.
   const uint64_t sizes[4] = {node_bytes, prim_bytes, material_bytes, light_bytes};
-  uint64_t hash = 0;
-  {
-    const void* bufs[4] = {nodes, prims, materials, lights};
-    for (int k = 0; k < 4; k++) hash = hash_bytes(bufs[k], sizes[k], hash + (uint64_t)k);
-  }
+  const void* const bufs[4] = {nodes, prims, materials, lights};
+  const uint64_t hash = known_hash ? *known_hash : hash_scene(bufs, sizes);
   if (ctx->has_scene && hash == ctx->scene_hash && memcmp(sizes, ctx->scene_sizes, sizeof(sizes)) == 0 && !getenv("LT_SCENE_ALWAYS_UPLOAD")) {
     ctx->scene_reused++;
     return LT_OK;
@@ -1173,6 +1231,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
     auto it = ctx->shadow_modes.find(shadowKey);
     shadowMode = it == ctx->shadow_modes.end() ? -1 : it->second;
   }
+  if (shadowMode == 3 && d->program != LT_PROGRAM_ACCUMULATOR) shadowMode = 0;   // (queued shadow rays are accumulator's)
   sc.shadowPackets = shadowMode > 0 ? (uint32_t)shadowMode : 0u;
   ctx->mean_pairs = 0;
   LT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, s));
@@ -1356,16 +1415,76 @@ extern "C" int lt_hip_render_device(lt_hip_context* ctx, const lt_hip_render_des
   return render_on_stream(ctx, desc, out_device, out_bytes, (hipStream_t)hip_stream);
 }
 
-extern "C" int lt_hip_render(lt_hip_context* ctx, const lt_hip_render_desc* desc, float* out_host, uint64_t out_bytes) {
-  if (!ctx) return LT_ERR_INVALID_ARGUMENT;
+// The read-back of lt_hip_render: device -> the context's pinned buffer in eight pieces (enqueued behind the kernels), each piece
+// copied on to the caller's buffer by a few host threads as soon as it has arrived, so that the link and the host's copy overlap.
+// LT_PINNED_READBACK=0: one hipMemcpyAsync into the caller's (pageable) buffer, as round 2 did it.
+static int enqueue_readback(lt_hip_context* ctx, uint64_t need, float* out_host, bool& staged) {
+  const char* pe = getenv("LT_PINNED_READBACK");
+  staged = !(pe && atoi(pe) == 0) && need >= (1u << 20);
+  if (staged && ctx->h_out_bytes < need) {
+    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+    ctx->h_out = nullptr;
+    ctx->h_out_bytes = 0;
+    if (hipHostMalloc(&ctx->h_out, need, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->h_out = nullptr;
+      staged = false;
+    } else {
+      ctx->h_out_bytes = need;
+    }
+  }
+  if (!staged) {
+    LT_HIP_CHECK(ctx, hipMemcpyAsync(out_host, ctx->d_out, need, hipMemcpyDeviceToHost, ctx->stream));
+    return LT_OK;
+  }
+  for (hipEvent_t& e : ctx->out_ev) if (!e) LT_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  const uint64_t piece = ((need + 7) / 8 + 4095) / 4096 * 4096;
+  for (int k = 0; k < 8; k++) {
+    const uint64_t off = std::min(need, (uint64_t)k * piece), n = std::min(piece, need - off);
+    if (n) LT_HIP_CHECK(ctx, hipMemcpyAsync((char*)ctx->h_out + off, (const char*)ctx->d_out + off, n, hipMemcpyDeviceToHost, ctx->stream));
+    LT_HIP_CHECK(ctx, hipEventRecord(ctx->out_ev[k], ctx->stream));
+  }
+  return LT_OK;
+}
+static int finish_readback(lt_hip_context* ctx, uint64_t need, float* out_host, bool staged) {
+  if (!staged) {
+    LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return LT_OK;
+  }
+  const uint64_t piece = ((need + 7) / 8 + 4095) / 4096 * 4096;
+  const int threads = std::max(1, std::min(8, host_threads()));
+  std::atomic<int> failed{0};
+  auto work = [&](int t, int of) {
+    (void)hipSetDevice(ctx->device);
+    for (int k = 0; k < 8; k++) {
+      if (hipEventSynchronize(ctx->out_ev[k]) != hipSuccess) { failed = 1; return; }
+      const uint64_t off = std::min(need, (uint64_t)k * piece), n = std::min(piece, need - off);
+      const uint64_t lo = off + n * (uint64_t)t / (uint64_t)of, hi = off + n * (uint64_t)(t + 1) / (uint64_t)of;
+      memcpy((char*)out_host + lo, (const char*)ctx->h_out + lo, (size_t)(hi - lo));
+    }
+  };
+  std::vector<std::thread> pool;
+  int started = 1;
+  try {
+    for (; started < threads; started++) pool.emplace_back(work, started, threads);
+  } catch (...) {
+  }
+  work(0, threads);
+  for (std::thread& th : pool) th.join();
+  for (int t = started; t < threads; t++) work(t, threads);   // (the slices of the threads that could not be had)
+  LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (failed) return fail(ctx, LT_ERR_HIP, "read-back failed");
+  return LT_OK;
+}
+
+static int render_to_host(lt_hip_context* ctx, const lt_hip_render_desc* desc, float* out_host, uint64_t out_bytes, uint64_t& need, bool& staged) {
   if (!out_host) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "output pointer is NULL");
   TilePlan p;
   std::string msg;
   int rc = plan_tiles(desc, p, msg);
   if (rc) return fail(ctx, rc, msg);
-  const uint64_t need = p.floats * sizeof(float);
+  need = p.floats * sizeof(float);
   if (out_bytes < need) return fail(ctx, LT_ERR_BUFFER_TOO_SMALL, "outputBufferSize smaller than W*H*depth floats");
-  const auto t0 = std::chrono::steady_clock::now();
   LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (ctx->d_out_bytes < need) {
     if (ctx->d_out) LT_HIP_CHECK(ctx, hipFree(ctx->d_out));
@@ -1381,12 +1500,69 @@ extern "C" int lt_hip_render(lt_hip_context* ctx, const lt_hip_render_desc* desc
     LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_out, 0, need, ctx->stream));
   rc = render_on_stream(ctx, desc, ctx->d_out, need, ctx->stream);
   if (rc) return rc;
-  LT_HIP_CHECK(ctx, hipMemcpyAsync(out_host, ctx->d_out, need, hipMemcpyDeviceToHost, ctx->stream));
-  LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return enqueue_readback(ctx, need, out_host, staged);
+}
+
+extern "C" int lt_hip_render(lt_hip_context* ctx, const lt_hip_render_desc* desc, float* out_host, uint64_t out_bytes) {
+  if (!ctx) return LT_ERR_INVALID_ARGUMENT;
+  const auto t0 = std::chrono::steady_clock::now();
+  uint64_t need = 0;
+  bool staged = false;
+  int rc = render_to_host(ctx, desc, out_host, out_bytes, need, staged);
+  if (rc) return rc;
+  rc = finish_readback(ctx, need, out_host, staged);
+  if (rc) return rc;
   rc = finish_pending(ctx);
   if (rc) return rc;
   ctx->last.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return LT_OK;
+}
+
+// lt_hip_set_scene + lt_hip_render in one call, as the plugin's render() needs them (the reference hands over its scene on every
+// call, renderer_opencl.cpp:107-120): when the buffers have the resident scene's sizes, the frame is rendered and read back ON
+// THE ASSUMPTION that nothing changed while this thread hashes the buffers; the hash decides whether the frame stands.  It
+// nearly always does -- and then the hash of 140 MB of scene has cost nothing, hidden behind the frame's 17 ms -- or the scene
+// is uploaded and the frame rendered again.
+extern "C" int lt_hip_render_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims, uint64_t prim_bytes,
+                                   const void* materials, uint64_t material_bytes, const void* lights, uint64_t light_bytes,
+                                   const lt_hip_render_desc* desc, float* out_host, uint64_t out_bytes) {
+  if (!ctx) return LT_ERR_INVALID_ARGUMENT;
+  if (!nodes || !prims || !materials || !lights) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "NULL scene buffer");
+  try {
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint64_t sizes[4] = {node_bytes, prim_bytes, material_bytes, light_bytes};
+    const void* const bufs[4] = {nodes, prims, materials, lights};
+    const bool continues = desc && desc->frame_count && desc->accumulate && desc->accumulate_base > 0;   // (reads the caller's buffer: no second try)
+    const bool speculate = ctx->has_scene && memcmp(sizes, ctx->scene_sizes, sizeof(sizes)) == 0 && !getenv("LT_SCENE_ALWAYS_UPLOAD") && !continues;
+    uint64_t need = 0;
+    bool staged = false;
+    int rc;
+    if (speculate) {
+      rc = render_to_host(ctx, desc, out_host, out_bytes, need, staged);
+      if (rc) return rc;
+      const uint64_t hash = hash_scene(bufs, sizes);   // (while the GPU renders)
+      rc = finish_readback(ctx, need, out_host, staged);
+      if (rc) return rc;
+      if (hash == ctx->scene_hash) {
+        ctx->scene_reused++;
+        rc = finish_pending(ctx);
+        if (rc) return rc;
+        ctx->last.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return LT_OK;
+      }
+      rc = finish_pending(ctx);
+      if (rc) return rc;
+      rc = set_scene_impl(ctx, nodes, node_bytes, prims, prim_bytes, materials, material_bytes, lights, light_bytes, &hash);
+    } else {
+      rc = set_scene_impl(ctx, nodes, node_bytes, prims, prim_bytes, materials, material_bytes, lights, light_bytes, nullptr);
+    }
+    if (rc) return rc;
+    rc = lt_hip_render(ctx, desc, out_host, out_bytes);
+    if (rc == LT_OK) ctx->last.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+  } catch (const std::exception& e) {
+    return fail(ctx, LT_ERR_HIP, std::string("lt_hip_render_scene: ") + e.what());
+  }
 }
 
 extern "C" int lt_hip_untile(lt_hip_context* ctx, const float* gathered, uint64_t floats_per_rank, uint32_t n_ranks, uint32_t width,

@@ -662,13 +662,25 @@ __device__ __forceinline__ bool own_walk_step(const SceneDev& sc, const Ray& ray
       }
     }
   } else {
+    // the links of the slots entered: the last one stays in a register and is the next record (leaves sit in a group's last
+    // slots: they come first), the others wait on the stack
     const uint4 slot[4] = {s0, s1, s2, s3};
+    uint32_t next = 0u;
+    bool have = false;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (own16_box_test(slot[k], w.qr, w.negx, w.negy, w.negz) && slot[k].w != w.ignLink) {
-        if (sp < ROWS) col[sp * kBlock] = (int)slot[k].w; else deep[sp - ROWS] = (int)slot[k].w;
-        sp++;
+        if (have) {
+          if (sp < ROWS) col[sp * kBlock] = (int)next; else deep[sp - ROWS] = (int)next;
+          sp++;
+        }
+        next = slot[k].w;
+        have = true;
       }
+    }
+    if (have) {
+      e = next;
+      return false;
     }
   }
   if (sp == 0) return true;

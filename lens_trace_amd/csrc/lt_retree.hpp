@@ -20,6 +20,8 @@
 // child-pair kernel read it as they read the caller's buffer.  Without clipping, the expected number of nodes a ray visits is
 // exactly the surface-area sum the heuristic minimises.  Height is bounded (the walks' LDS stacks are as deep as the tree).
 #pragma once
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -43,6 +45,13 @@ struct Node {   // LinearBVHNode (include/lens_trace/acceleration_structure_expl
 static_assert(sizeof(Node) == 32, "LinearBVHNode is 32 bytes");
 
 constexpr int kBins = 32;
+
+// CPUs this process may run on (its affinity mask: a container's share, not the machine's core count)
+inline int available_cpus() {
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) return std::max(1, CPU_COUNT(&set));
+  return (int)std::max(1u, std::thread::hardware_concurrency());
+}
 
 inline int ceil_log2(uint32_t x) {
   int l = 0;
@@ -240,7 +249,7 @@ inline int build(const void* nodes, uint32_t n_nodes, int maxHeight, int slack, 
   // leaves owns out[node, node + 2k - 1) and order[start, end): nothing is shared)
   if (threads <= 0) {
     const char* e = getenv("LT_RETREE_THREADS");
-    threads = e ? std::max(1, std::min(64, atoi(e))) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    threads = e ? std::max(1, std::min(64, atoi(e))) : std::min(16, available_cpus());
   }
   if (n < 50000u) threads = 1;
   if (threads == 1) return build_range(nd, centroid.data(), order, out.data(), Range{0, n, 0, 0}, heightLimit);
@@ -273,7 +282,10 @@ inline int build(const void* nodes, uint32_t n_nodes, int maxHeight, int slack, 
     }
   };
   std::vector<std::thread> pool;
-  for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+  try {
+    for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+  } catch (...) {   // (no more threads to be had -- a pids limit, eight ranks on one host: whoever exists builds; the tree is the same)
+  }
   worker();
   for (std::thread& th : pool) th.join();
   return height;
@@ -376,8 +388,16 @@ inline void reference_order(const void* nodes, uint32_t n_prims, std::vector<uin
       stack.push_back(neg ? (uint32_t)p.off : i + 1);   // near child
     }
   };
+  // eight writers, eight disjoint sets of words; small trees, and octants no thread could be had for, on this thread
   std::vector<std::thread> pool;
-  for (uint32_t o = 0; o < 8; o++) pool.emplace_back(one, o);   // (eight writers, eight disjoint sets of words)
+  uint32_t o = 0;
+  if (n_prims >= 50000u && available_cpus() > 1) {
+    try {
+      for (; o < 7; o++) pool.emplace_back(one, o);
+    } catch (...) {
+    }
+  }
+  for (; o < 8; o++) one(o);
   for (std::thread& th : pool) th.join();
 }
 

@@ -70,20 +70,11 @@ void RendererHIP::render(void* pRenderProperties) {
       break;
     }
   }
-  // lt_hip_set_scene hashes the buffers and keeps the resident copy when nothing changed; a caller that versions its scene
-  // skips even that
+  // A caller that versions its scene has it looked at only when the objects or the number change; anyone else hands it over with
+  // every frame (lt_hip_render_scene below: hashed in full while the frame renders, uploaded only when it changed).
   const uint64_t version = backend ? backend->sceneVersion : 0;
   const bool sameObjects = memcmp(key, cachedKey, sizeof(key)) == 0 && memcmp(size, cachedSize, sizeof(size)) == 0;
-  if (!(sameObjects && version != 0 && version == cachedVersion)) {
-    if (lt_hip_set_scene(context, key[0], size[0], key[1], size[1], key[2], size[2], key[3], size[3]) != LT_OK) {
-      printf("Kernel Error: %s\n", lt_hip_last_error(context));
-      memset(cachedKey, 0, sizeof(cachedKey));
-      return;
-    }
-    memcpy(cachedKey, key, sizeof(key));
-    memcpy(cachedSize, size, sizeof(size));
-    cachedVersion = version;
-  }
+  const bool known = sameObjects && version != 0 && version == cachedVersion;
 
   lt_hip_render_desc desc;
   memset(&desc, 0, sizeof(desc));
@@ -107,7 +98,15 @@ void RendererHIP::render(void* pRenderProperties) {
   }
   if (backend && backend->portableMath) desc.flags |= LT_RENDER_FLAG_PORTABLE_MATH;
   if (backend && backend->strictMath) desc.flags |= LT_RENDER_FLAG_STRICT_MATH;
-  if (lt_hip_render(context, &desc, (float*)props->pOutputBuffer, props->outputBufferSize) != LT_OK) {
+  const int rc = known ? lt_hip_render(context, &desc, (float*)props->pOutputBuffer, props->outputBufferSize)
+                       : lt_hip_render_scene(context, key[0], size[0], key[1], size[1], key[2], size[2], key[3], size[3], &desc,
+                                             (float*)props->pOutputBuffer, props->outputBufferSize);
+  if (rc != LT_OK) {
     printf("Kernel Error: %s\n", lt_hip_last_error(context));
+    if (!known) memset(cachedKey, 0, sizeof(cachedKey));
+    return;
   }
+  memcpy(cachedKey, key, sizeof(key));
+  memcpy(cachedSize, size, sizeof(size));
+  cachedVersion = version;
 }

@@ -132,15 +132,24 @@ class RendererHIP:
             raise ValueError("pOutputBuffer must be contiguous float32")
         a = props.pAccelerationStructureExplicit
         m = props.pModel or a
-        # the reference re-uploads on every call; lt_hip_set_scene keeps the resident copy when every byte is unchanged
-        key = (id(a), id(m))
-        if not (props.sceneVersion and key == self._scene_key and props.sceneVersion == self._scene_version):
-            self.set_scene(a, props.pModel)
-            self._scene_version = props.sceneVersion
         program = self.resolve_program(props.kernelFilePath)
         d = make_desc(program, W, H, D, props.pCamera, props.kernelMode, props.frameFirst, props.frameCount,
                       props.accumulate, props.accumulateBase, None, props.giMaxDepth, props.collectStats, props.pixelCounters, props.portableMath, props.strictMath)
-        self._check(self._L.lt_hip_render(self._ctx, ctypes.byref(d), out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+        # the reference uploads its scene on every call; a caller that versions its scene has it looked at only when the objects
+        # or the number change, anyone else hands it over with the frame (lt_hip_render_scene: hashed in full while the frame
+        # renders, uploaded -- and the frame rendered again -- only when a byte changed)
+        key = (id(a), id(m))
+        if props.sceneVersion and key == self._scene_key and props.sceneVersion == self._scene_version:
+            self._check(self._L.lt_hip_render(self._ctx, ctypes.byref(d), out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+            return
+        arrs = [np.ascontiguousarray(x) for x in (a.nodes, a.prims, m.materials, a.lights)]
+        args = []
+        for x in arrs:
+            args += [x.ctypes.data_as(ctypes.c_void_p), x.nbytes]
+        self._check(self._L.lt_hip_render_scene(self._ctx, *args, ctypes.byref(d), out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+        self._scene_refs = (a, m)
+        self._scene_key = key
+        self._scene_version = props.sceneVersion
 
     # -- device-resident variants (bench / multi-GPU) -----------------------------------------------------
     def output_floats(self, desc):

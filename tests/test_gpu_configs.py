@@ -132,3 +132,89 @@ def test_config5_colonnade_4k_256_progressive_frames(renderer):
     rows_equal_oracle(single, s, sc.camera_with_frame(s.camera, 200), W, H, po.ACCUMULATOR, (10, 1080, 2000))
     # a 256-sample mean is smoother than one sample: smaller mean absolute horizontal gradient
     assert np.abs(np.diff(whole, axis=1)).mean() < np.abs(np.diff(single, axis=1)).mean()
+
+
+# ---- the configurations at their stated sizes against the reference's OWN kernels, default flavour ----
+def _default_props():
+    from lens_trace_amd.renderer import RenderPropertiesHIP as DefaultFlavourProps
+    return DefaultFlavourProps
+
+
+def _need_ref(kernel):
+    from oracle import ref_gpu
+    if not ref_gpu.available(kernel, "default"):
+        pytest.skip("oracle/_ref/%s.default.co not built (needs /root/reference at build time)" % kernel)
+    return ref_gpu
+
+
+def test_config1_cornell_basic_512_matches_the_reference_kernel(renderer):
+    """BASELINE config 1 at its stated size (Cornell box, primary rays only, 512x512) against basic.cl
+    (resources/kernels/opencl/basic.cl:279-342) as the reference builds it, and against the CPU oracle in the portable flavour."""
+    ref_gpu = _need_ref("basic")
+    s = sc.load_ltsb(os.path.join(GOLDEN, "cornell_box_O0.ltsb")).validate()
+    W = H = 512
+    cam = sc.camera_bytes(0.0, 2.5, -50.0, 0.0, 0.0, 0.0, 0)
+    got = np.empty((H, W, 3), dtype=np.float32)
+    renderer.render(_default_props()("basic.cl", (W, H, 3), got, s, pCamera=cam))
+    assert int((got != ref_gpu.render(s, cam, W, H, "basic", "default")).sum()) == 0
+    portable = np.empty((H, W, 3), dtype=np.float32)
+    renderer.render(RenderPropertiesHIP("basic.cl", (W, H, 3), portable, s, pCamera=cam))
+    assert np.array_equal(portable, po.render(s, cam, W, H, po.BASIC, threads=8))
+
+
+def test_config3_blob_1080p_matches_the_reference_accumulator_kernel(renderer):
+    """BASELINE config 3's scene and size (69 950-triangle blob in a box, 1920x1080) against accumulator.cl
+    (examples/accumulator/resources/kernels/accumulator.cl:132-217, :219-318) as the reference builds it: one whole frame, and the
+    running mean of four through the fused launch against the reference's frames folded in float32."""
+    ref_gpu = _need_ref("accumulator")
+    s = synth.blob_in_box().validate()
+    W, H = 1920, 1080
+    Props = _default_props()
+    acc = None
+    for k in range(4):
+        cam = sc.camera_with_frame(s.camera, 1 + k)
+        c = ref_gpu.render(s, cam, W, H, "accumulator", "default")
+        if k == 0:
+            got = np.empty((H, W, 3), dtype=np.float32)
+            renderer.render(Props(ACC, (W, H, 3), got, s, pCamera=cam))
+            assert int((got != c).sum()) == 0
+        acc = c if k == 0 else ((c + acc * np.float32(k)) / np.float32(k + 1)).astype(np.float32)
+    got = np.empty((H, W, 3), dtype=np.float32)
+    renderer.render(Props(ACC, (W, H, 3), got, s, pCamera=s.camera, frameFirst=1, frameCount=4, accumulate=True))
+    assert int((got != acc).sum()) == 0
+
+
+def test_config5_colonnade_4k_matches_the_reference_accumulator_kernel(renderer, monkeypatch):
+    """BASELINE config 5's scene and size (255 k-triangle colonnade, 3840x2160), one frame, against accumulator.cl as the reference
+    builds it -- with the shadow rays through the walk the library picks and through the queue (lt_trace_kernel)."""
+    ref_gpu = _need_ref("accumulator")
+    s = synth.colonnade().validate()
+    W, H = 3840, 2160
+    cam = sc.camera_with_frame(s.camera, 5)
+    ref = ref_gpu.render(s, cam, W, H, "accumulator", "default")
+    for forced in (None, "3"):
+        if forced:
+            monkeypatch.setenv("LT_SHADOW_PACKETS", forced)
+        got = np.empty((H, W, 3), dtype=np.float32)
+        renderer.render(_default_props()(ACC, (W, H, 3), got, s, pCamera=cam))
+        assert int((got != ref).sum()) == 0, "LT_SHADOW_PACKETS=%s" % forced
+
+
+def test_wall_1m_triangles_global_illumination_1080p_matches_the_reference_kernel(renderer, monkeypatch):
+    """The 1 002 530-triangle wall at 1920x1080 through global_illumination.cl
+    (examples/global_illumination/resources/kernels/global_illumination.cl:241-375, 16 bounces) as the reference builds it: the
+    wavefront pipeline -- extension and shadow rays through lt_trace_kernel over the 4-wide groups of the own hierarchy, equal-t
+    ties by the reference's leaf order on a 22-level tree -- its one-kernel bounce stage, and the single kernel."""
+    ref_gpu = _need_ref("global_illumination")
+    s = synth.heightfield_wall(708).validate()
+    W, H = 1920, 1080
+    cam = sc.camera_with_frame(s.camera, 2)
+    ref = ref_gpu.render(s, cam, W, H, "global_illumination", "default")
+    for env in ({"LT_GI_MEGAKERNEL": "0"}, {"LT_GI_MEGAKERNEL": "0", "LT_GI_TRACE": "0"}, {"LT_GI_MEGAKERNEL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = np.empty((H, W, 3), dtype=np.float32)
+        renderer.render(_default_props()(GI, (W, H, 3), got, s, pCamera=cam))
+        ndiff = int((got != ref).sum())
+        assert ndiff == 0, "%s: %d of %d floats differ from the reference kernel" % (env, ndiff, ref.size)
+        monkeypatch.delenv("LT_GI_TRACE", raising=False)

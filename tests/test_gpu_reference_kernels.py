@@ -213,7 +213,7 @@ def test_global_illumination_pipeline_on_a_big_scene_matches_reference(renderer,
             assert int((got != ref).sum()) == 0, "%s LT_GI_MEGAKERNEL=%s: rms %.3g" % (build, mega, rms(got, ref))
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("LT_FUZZ_SEEDS", "12"))))   # LT_FUZZ_SEEDS=300 for a long soak
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LT_FUZZ_SEEDS", "64"))))   # LT_FUZZ_SEEDS=300 for a long soak
 def test_fuzz_random_scenes_against_the_reference_kernels(renderer, monkeypatch, seed):
     """The seeded random scenes of tests/test_gpu_edge_cases.py (degenerate and sliver triangles, lens materials, random
     cameras, odd image sizes, both kernel modes) through the reference's own kernel files on this GPU: the default flavour

@@ -1,6 +1,6 @@
 # A/B of two builds of the library in ONE gpurun call (same box, same clocks): LT_HIP_LIBRARY selects the build.
 # usage: bash tests/tools/ab_libs.sh <libA.so> <libB.so> [quick]
-B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-soup"
+B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-soup --no-e2e"
 j='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); c=d["config"]; print(d["value"], d["ms_per_step"], c.get("shadow_ray_walk"))'
 for lib in "$1" "$2"; do
   export LT_HIP_LIBRARY=$PWD/$lib

@@ -3,7 +3,7 @@
 B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 j='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); c=d["config"]; print(d["value"], d["ms_per_step"], c.get("shadow_ray_walk"), "soup", c.get("soup_mrays_per_s"), c.get("soup_frame_ms"), c.get("soup_shadow_ray_walk"), "build_ms", c.get("own_hierarchy_build_ms"))'
 echo "wall accumulator 4K 16 spp: $($B 2>/dev/null | python -c "$j")"
-B="$B --no-soup"
+B="$B --no-soup --no-e2e"
 echo "wall GI 4K, 16 spp, 16 bounces: $($B --program global_illumination 2>/dev/null | python -c "$j")"
 echo "wall accumulator, shadow rays per lane: $(LT_SHADOW_PACKETS=0 $B 2>/dev/null | python -c "$j")"
 echo "soup accumulator, shadow rays per lane: $(LT_SHADOW_PACKETS=0 $B --scene soup 2>/dev/null | python -c "$j")"

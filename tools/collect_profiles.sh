@@ -19,10 +19,10 @@ OUT=gpurun_out/prof_$ROUND
 rm -rf "$OUT"      # (a pass directory must hold ONE run: the summaries average over every csv they find)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-soup $EXTRA"
+B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-soup --no-e2e $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/stats.log 2>&1
 echo "stats pass done"
-B1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-soup $EXTRA"
+B1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-soup --no-e2e $EXTRA"
 pass() {   # name, counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- $B1 > $OUT/$name.log 2>&1 || { echo "pass $name FAILED (see $OUT/$name.log)"; tail -3 $OUT/$name.log; return 0; }
