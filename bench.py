@@ -45,24 +45,59 @@ SHADOW_WALKS = {0: "per lane", 1: "any-hit packets", 2: "chosen per wavefront", 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
+# what a launch runs besides the workload: the kernel sources and the environment switches that pick other walks / hierarchies
+ENV_PINS = ("LT_RETREE", "LT_RETREE_SLACK", "LT_SHADOW_PACKETS", "LT_SHADOW_SPREAD", "LT_PERSISTENT", "LT_FUSED_FRAMES", "LT_SQUARE_MAJOR",
+            "LT_NATURAL_ORDER", "LT_GI_MEGAKERNEL", "LT_GI_TRACE", "LT_GI_LDS_SCENE", "LT_TRACE_REFILL", "LT_DEBUG_LDS_ROWS")
+
+
+def build_identity(ignore_pins=("LT_SHADOW_PACKETS",)):
+    """sha256 over lens_trace_amd/csrc/* (what liblenstrace-hip.so is built from) and the LT_* switches in force.  Stored in
+    the counter summaries under profiles/ (tools/profile_summary.py) and compared here: counters of another build say nothing
+    about this one.  (LT_SHADOW_PACKETS is left out of the comparison: the profiler passes pin the walk the library picks for
+    the workload by itself, so that no launch of a pass is a timing run; the summary records it.)"""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "lens_trace_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        h.update(f.encode())
+        h.update(open(os.path.join(src, f), "rb").read())
+    pins = {k: os.environ[k] for k in ENV_PINS if k in os.environ}
+    return {"csrc_sha256": h.hexdigest()[:16], "env": pins, "compared_env": {k: v for k, v in pins.items() if k not in ignore_pins}}
+
+
 def _latest_profile(name, workload_key):
-    """profiles/r*/<name> of the newest round whose `workload` is this run's (PMC counters cannot be read from inside this
-    process: tools/collect_profiles.sh collects them for this same command in separate rocprofv3 passes)."""
+    """profiles/r<N>/<name> of the newest round (numerically) whose `workload` is this run's AND whose build is this build
+    (kernel sources and environment switches: build_identity) -- PMC counters cannot be read from inside this process:
+    tools/collect_profiles.sh collects them for this same command in separate rocprofv3 passes.  Sub-directories of a round hold
+    other workloads / switches and are matched the same way.  Returns (summary or None, why not)."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)) + glob.glob(os.path.join(ROOT, "profiles", "r*", "*", name))):
+    import re
+    me = build_identity()
+    best, why = None, "no counter summary of this workload under profiles/"
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*", name)) + glob.glob(os.path.join(ROOT, "profiles", "r*", "*", name))
+
+    def order(f):
+        m = re.search(r"profiles/r(\d+)", f.replace(os.sep, "/"))
+        return (int(m.group(1)) if m else -1, f.count(os.sep), f)
+    for f in sorted(files, key=order):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("workload", "").startswith(workload_key):
-            best = d
-            best["_file"] = os.path.relpath(f, ROOT)
-    return best
+        if not d.get("workload", "").startswith(workload_key):
+            continue
+        b = d.get("build") or {}
+        if b.get("csrc_sha256") != me["csrc_sha256"] or b.get("compared_env", {}) != me["compared_env"]:
+            why = "profile stale: %s was collected from another build of the kernels (csrc %s, env %s; this build: %s, %s)" % (
+                os.path.relpath(f, ROOT), b.get("csrc_sha256"), b.get("compared_env"), me["csrc_sha256"], me["compared_env"])
+            continue
+        best = d
+        best["_file"] = os.path.relpath(f, ROOT)
+    return best, (None if best else why)
 
 
 def measured_traffic(workload_key):
-    d = _latest_profile("hbm_traffic.json", workload_key)
+    d, _ = _latest_profile("hbm_traffic.json", workload_key)
     return d.get("hbm_bytes_per_launch") if d else None
 
 
@@ -70,7 +105,7 @@ def roofline(workload_key, kernel_name, launch_ms, launches_per_step, spp, alg_b
     """See the module docstring."""
     alg_gbs = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
     traffic = measured_traffic(workload_key) if single_gpu else None
-    prof = _latest_profile("issue_profile.json", workload_key) if single_gpu else None
+    prof, stale = _latest_profile("issue_profile.json", workload_key) if single_gpu else (None, None)
     out = {"kernel": kernel_name, "launch_ms": round(launch_ms, 4), "launches_per_step": launches_per_step,
            "samples_per_launch": spp / launches_per_step, "traffic": traffic,
            "algorithmic_bytes_per_launch": alg_bytes_per_launch, "algorithmic_gbs": round(alg_gbs, 1)}
@@ -93,10 +128,12 @@ def roofline(workload_key, kernel_name, launch_ms, launches_per_step, spp, alg_b
         out["shader_clock_ghz"] = round(clock, 3)
         out["source"] = prof["_file"]
     else:
-        # no counter profile of this workload in the tree: only the HBM side can be stated
+        # no counter profile of this workload AND this build in the tree: only the HBM side can be stated, if that
         hbm = (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None
         out = dict({"bound": "hbm", "achieved": round(hbm, 1) if hbm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(hbm / HBM_PEAK_GBS, 4) if hbm else None}, **out)
+        if stale:
+            out["note"] = stale
     return out
 
 
@@ -303,6 +340,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_s = [float(x) for x in t.tolist()]
 
+    # The latency of ONE frame, outside the timed region: a few steps one at a time (enqueue, gather, untile, synchronize, barrier),
+    # MAX over ranks.  With one step in flight this is what ms_per_step is; with two, ms_per_step is the pipelined period and a frame
+    # takes longer than that from its first launch to its last pixel.
+    lat_steps = max(2, min(args.steps, 5))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    lat_render_ms, lat_launches = 0.0, 0
+    for _ in range(lat_steps):
+        step(d, slots[0])
+        torch.cuda.synchronize()
+        st_ = slots[0].r.stats()
+        lat_render_ms += st_["render_ms"]
+        lat_launches += st_["kernel_launches"]
+        if world > 1:
+            dist.barrier()
+    lat = torch.tensor([(time.perf_counter() - t0) / lat_steps], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(lat, op=dist.ReduceOp.MAX)
+    frame_latency_ms = float(lat.item()) * 1e3
+    if args.in_flight > 1:     # (HIP-event times of overlapping steps include the neighbour's work: the kernel's own time comes from these steps)
+        render_ms, launches = lat_render_ms * args.steps / lat_steps, int(round(lat_launches * args.steps / lat_steps))
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays_total * args.steps / elapsed / 1e6
@@ -339,8 +400,12 @@ def main():
                        "workload_key": "%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program),   # (names the profiles/ summaries of this workload)
                        "triangles": scene.n_prims, "bvh_nodes": scene.n_nodes, "bvh_split": args.bvh, "width": W, "height": H, "spp": args.spp,
                        "rays_per_frame": rays_total, "node_visits_per_ray": nodes_total / rays_total,
-                       "tri_tests_per_ray": tris_total / rays_total, "kernel_only_mrays_per_s": round(rays_total * args.steps / kernel_s / 1e6, 2),
-                       "frame_ms": round(ms_per_step, 3), "steps_in_flight": args.in_flight,
+                       "tri_tests_per_ray": tris_total / rays_total,
+                       # (per-call HIP-event times include the neighbouring step's work when two steps overlap: not reported then)
+                       "kernel_only_mrays_per_s": round(rays_total * args.steps / kernel_s / 1e6, 2) if args.in_flight == 1 else None,
+                       # frame ms, both ways: the period at which finished frames leave the job (= ms_per_step; with two steps in
+                       # flight, two frames overlap) and the latency of one frame rendered alone, first launch to last pixel at the root
+                       "frame_period_ms": round(ms_per_step, 3), "frame_latency_ms": round(frame_latency_ms, 3), "steps_in_flight": args.in_flight,
                        # which of its three (pixel-identical) walks the library timed fastest for this scene's shadow rays
                        "shadow_ray_walk": SHADOW_WALKS.get(shadow_walk, "not timed"),
                        # the backend's own hierarchy over the caller's leaves: height, host build time at set_scene (not in any step)

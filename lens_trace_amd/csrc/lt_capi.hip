@@ -1256,12 +1256,20 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       // packet walks park their stack register in the first of them).
       ctx->lds_ref_bytes = (uint32_t)std::max(kPacketRows, std::min(ctx->bvh_height, kLdsStack)) * kBlock * sizeof(int);
       uint32_t lds = stats ? ctx->lds_ref_bytes : (uint32_t)std::max(kPacketRows, kOwnRows) * kBlock * sizeof(int);
-      // (occupancy experiments: MORE rows than the launch needs, never fewer -- the counting kernels' per-lane stacks live there)
-      if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) lds = std::max(lds, (uint32_t)std::max(0, std::min(160, atoi(e))) * (uint32_t)(kBlock * sizeof(int)));
+      // LT_DEBUG_LDS_ROWS (occupancy experiments, tests): more rows than the launch needs, for every kernel; FEWER only for the
+      // counting kernels, whose deep-tree form keeps what does not fit in private memory (the others index their rows with
+      // compile-time bounds).  The kernel is told what it got (FrameParams::ldsRows) and the form is chosen from that.
+      if (const char* e = getenv("LT_DEBUG_LDS_ROWS")) {
+        const uint32_t want = (uint32_t)std::max(1, std::min(160, atoi(e))) * (uint32_t)(kBlock * sizeof(int));
+        lds = stats ? want : std::max(lds, want);
+      }
+      fp.ldsRows = lds / (uint32_t)(kBlock * sizeof(int));
+      LaunchConfig lcl = lc;
+      lcl.deep = stats && (uint32_t)ctx->bvh_height > fp.ldsRows;   // (the non-counting kernels have no deep-tree form: they keep no per-lane stack of the caller's tree in LDS)
       if (giWavefront) {
         SceneDev scGi = sc;
         scGi.shadowPackets = spe ? sc.shadowPackets : 0u;   // the pipeline's bounce stages cast incoherent shadow rays: per lane
-        const int grc = launch_gi_sets(ctx, s, scGi, fp, lc, lds, giPixels, gi25Sets ? samplesPerSet : 0u, p.floats, out_launch, out_device, launches);
+        const int grc = launch_gi_sets(ctx, s, scGi, fp, lcl, lds, giPixels, gi25Sets ? samplesPerSet : 0u, p.floats, out_launch, out_device, launches);
         if (grc) return grc;
         launches--;   // (counted again below)
       } else if (userProgram) {
@@ -1277,12 +1285,12 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
         // the kernel that blacks out the occluded samples.
         auto launch_render = [&](const FrameParams& fpl, dim3 g) {
           switch (d->program) {
-            case LT_PROGRAM_BASIC: launch_program<kBasic>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
-            case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
-            case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
-            case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
-            case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
-            default: launch_program<kCustom>(lc, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            case LT_PROGRAM_BASIC: launch_program<kBasic>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            default: launch_program<kCustom>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
           }
         };
         const bool queueOk = d->program == LT_PROGRAM_ACCUMULATOR && persistent && !stats && ctx->d_rank8 != nullptr && fp.accumulateN < 0 &&

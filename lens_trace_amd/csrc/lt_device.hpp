@@ -371,22 +371,24 @@ __device__ __forceinline__ bool intersect_triangle_anyhit(const float4 t0, const
   return ok && (tt < tmax);
 }
 
-// The per-lane traversal stack: entries [0,kLdsStack) live in LDS (column `lane`, row stride kBlock, so
-// every wave access is one conflict-free row), deeper entries (only for BVHs deeper than kLdsStack, chosen
-// by the host from the scene's measured height) in a per-lane scratch array.
+// The per-lane traversal stack: entries [0, rows) live in LDS (column `lane`, row stride kBlock, so every wave access is one
+// conflict-free row; rows = what the launch allocated, at most kLdsStack), deeper entries (only in the DEEP form, which the host
+// launches whenever the scene's measured height exceeds the rows) in a per-lane scratch array.
 template <bool B, class T, class F> struct SelectType { using type = T; };
 template <class T, class F> struct SelectType<false, T, F> { using type = F; };
 
 template <bool DEEP>
 struct Stack {
   int* lds;            // &lds_stack[threadIdx.x]
-  int deep[DEEP ? (kMaxStack - kLdsStack) : 1];
+  int rows;            // LDS rows the launch gave each lane (FrameParams::ldsRows): the DEEP form keeps entries [0, rows) there and the
+                       // rest in private memory, whatever the host allocated; the other form is launched only when rows >= the tree's height
+  int deep[DEEP ? kMaxStack : 1];
   __device__ __forceinline__ void push(int sp, int v) {
-    if (!DEEP || sp < kLdsStack) lds[sp * kBlock] = v; else deep[sp - kLdsStack] = v;
+    if (!DEEP || sp < rows) lds[sp * kBlock] = v; else deep[sp - rows] = v;
   }
   __device__ __forceinline__ int pop(int sp) {
-    if (!DEEP || sp < kLdsStack) return lds[sp * kBlock];
-    return deep[sp - kLdsStack];
+    if (!DEEP || sp < rows) return lds[sp * kBlock];
+    return deep[sp - rows];
   }
   // A stack position as the loop variable of the per-lane walk: the LDS row pointer itself when the whole stack is in LDS
   // (stepping it by a row is one add; an index would cost a shift-add per access), the entry index otherwise.
@@ -662,25 +664,16 @@ __device__ __forceinline__ bool own_walk_step(const SceneDev& sc, const Ray& ray
       }
     }
   } else {
-    // the links of the slots entered: the last one stays in a register and is the next record (leaves sit in a group's last
-    // slots: they come first), the others wait on the stack
+    // the links of the slots entered go on the stack (leaves sit in a group's last slots: they come off first).  (Keeping the last
+    // one in a register instead of pushing and popping it was measured: 5 % slower in lt_trace_kernel, 1 % faster in the render
+    // kernels' walks.)
     const uint4 slot[4] = {s0, s1, s2, s3};
-    uint32_t next = 0u;
-    bool have = false;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (own16_box_test(slot[k], w.qr, w.negx, w.negy, w.negz) && slot[k].w != w.ignLink) {
-        if (have) {
-          if (sp < ROWS) col[sp * kBlock] = (int)next; else deep[sp - ROWS] = (int)next;
-          sp++;
-        }
-        next = slot[k].w;
-        have = true;
+        if (sp < ROWS) col[sp * kBlock] = (int)slot[k].w; else deep[sp - ROWS] = (int)slot[k].w;
+        sp++;
       }
-    }
-    if (have) {
-      e = next;
-      return false;
     }
   }
   if (sp == 0) return true;
@@ -1272,6 +1265,7 @@ struct FrameParams {
   uint32_t tileW, tileH, tilesX, tileFirst, tileStride, tilesInCall;
   uint32_t blocksPerTileX, blocksPerTile;   // 8x8-pixel wavefront squares per image tile
   uint32_t totalSquares;                    // tilesInCall * blocksPerTile
+  uint32_t ldsRows;                         // 256-byte LDS rows of each wavefront in this launch (Stack::rows)
   uint32_t persistent;                      // != 0: waves pull squares from per-XCD queues instead of one square per workgroup
   // several samples in one launch (persistent mode): work item = (frame f, square), frame f uses frameCount + f and stores
   // its colours, un-accumulated, at out + f * frameStride; lt_running_mean_kernel folds them in frame order afterwards

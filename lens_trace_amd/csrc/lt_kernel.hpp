@@ -83,6 +83,7 @@ __device__ __forceinline__ void render_kernel_body(const SceneDev& sc, const Fra
   constexpr bool STATS = CFG::kStats;
   Stack<CFG::kDeep> st;
   st.lds = lds_stack + threadIdx.x;
+  st.rows = (int)fp.ldsRows;
   Counters c{};
 
   // Two ways to hand out the 8x8 squares, one loop (a single inlined copy of the renderer):
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_primary_kerne
   extern __shared__ int lds_stack[];
   Stack<CFG::kDeep> st;
   st.lds = lds_stack + threadIdx.x;
+  st.rows = (int)fp.ldsRows;
   Counters c{};
   const uint32_t n = fp.totalSquares, q = n / 8u, r = n % 8u;
   const uint32_t home = __builtin_amdgcn_s_getreg((3u << 11) | 20u) & 7u;
@@ -319,6 +321,7 @@ void lt_gi_bounce_kernel(SceneDev sc, FrameParams fp, GiParams gp, uint32_t dept
   extern __shared__ int lds_stack[];
   Stack<CFG::kDeep> st;
   st.lds = stage_lds_setup<CFG>(sc, gp.ldsRows, lds_stack);
+  st.rows = (int)gp.ldsRows;
   Counters c{};
   const GiQueue in = gp.q[depth & 1u], out = gp.q[(depth + 1u) & 1u];
   const uint32_t total = gp.counts[depth * kQueueStride];

@@ -38,6 +38,10 @@ def test_single_gpu_line_has_the_contract_keys():
     assert r["traffic"] is None and r["frac"] is None and r["bound"] == "hbm" and r["peak"] == 8000.0
     assert r["algorithmic_gbs"] > 0
     assert "soup_mrays_per_s" in d["config"] and d["config"]["soup_mrays_per_s"] > 0
+    # end to end (the reference's contract: the caller's host buffer is complete on return), and one frame's latency
+    cfg = d["config"]
+    assert cfg["e2e_frame_ms_host_buffer"] > 0 and cfg["e2e_frame_ms_plugin"] > 0 and cfg["scene_hash_ms"] > 0
+    assert cfg["frame_latency_ms"] > 0 and cfg["frame_period_ms"] == d["ms_per_step"] and cfg["steps_in_flight"] == 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "frames" in c["sample"]
     assert d["value"] > c["value"]
@@ -52,6 +56,8 @@ def test_two_ranks_on_one_gpu_through_gloo_count_the_same_rays():
                "--master-port", "29541", "bench.py", "--gpus", "2", "--no-cpu-baseline"] + SMALL,
               env={"LT_BENCH_BACKEND": "gloo", "LT_BENCH_SINGLE_DEVICE": "1"})
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    # two steps in flight: the period of finished frames and one frame's own latency are two numbers
+    assert two["config"]["steps_in_flight"] == 2 and two["config"]["frame_latency_ms"] > 0 and two["config"]["kernel_only_mrays_per_s"] is None
     assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
     assert "tiles interleaved over 2 GPUs" in two["config"]["workload"]
     assert "cpu_baseline" not in two

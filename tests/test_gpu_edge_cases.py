@@ -105,6 +105,18 @@ def test_deep_bvh_uses_the_spilling_stack(renderer, n):
         both(renderer, s, prog, 40, 24, CAM)
 
 
+def test_a_counting_launch_with_fewer_lds_rows_than_the_tree_is_high_spills_and_finishes(renderer, monkeypatch):
+    """LT_DEBUG_LDS_ROWS below the tree's height (round 2 hung a run that way: per-lane stack rows beyond the launch's LDS): the
+    kernel is told how many rows it got and the host launches the form that keeps the rest of a lane's stack in private memory.
+    One row for the Cornell box (height 9), pixels and per-pixel work counters against the oracle."""
+    from tests.conftest import GOLDEN
+    s = sc.load_ltsb(os.path.join(GOLDEN, "cornell_box_O0.ltsb")).validate()
+    for rows in ("1", "3", "40"):
+        monkeypatch.setenv("LT_DEBUG_LDS_ROWS", rows)
+        for prog in ("accumulator", "global_illumination"):
+            both(renderer, s, prog, 48, 32, CAM)
+
+
 def test_bvh_deeper_than_the_reference_stack_is_refused(renderer):
     prims = quad_prims(70)
     s = sc.Scene(caterpillar(prims).view(np.uint8).reshape(-1), prims.view(np.uint8).reshape(-1),

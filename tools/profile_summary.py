@@ -18,6 +18,9 @@ from collections import defaultdict
 
 out_dir = sys.argv[1]
 command = sys.argv[2] if len(sys.argv) > 2 else ""
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import build_identity   # noqa: E402  (hash of the kernel sources + the environment pins that change what a launch runs)
 
 
 def counters(name):
@@ -70,9 +73,16 @@ key = (bench.get("config") or {}).get("workload_key", "")
 
 if kern in passes["fetch"] and kern in passes["write"]:
     fetch_kb, write_kb = passes["fetch"][kern]["FETCH_SIZE"], passes["write"][kern]["WRITE_SIZE"]
+    # FETCH_SIZE counts fabric read requests at 64 bytes each.  Calibrated on this chip (tools/probes/gather_calib.hip,
+    # profiles/r3/gather_calibration.txt): a wide coalesced stream moves 128 bytes per request (the guide's x2), but the reads of
+    # these kernels -- per-lane gathers of 16..64-byte records and wave-uniform s_load_dwordx16 -- are counted at 62-64 bytes per
+    # 64-byte record: x1.  Only the running-mean kernel streams; it is not the dominant kernel.
+    streaming = "running_mean" in kern or "untile" in kern
+    factor = 2 if streaming else 1
     hbm = {"command": command, "kernel": kern, "workload": key, "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
-           "correction": "gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE as reported",
-           "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024), "launch_ms_under_profiler": ms}
+           "correction": "FETCH_SIZE = fabric read requests x 64 B; x%d for this kernel (gathers of <= 64-byte records and scalar loads are counted as "
+                         "they are, wide coalesced streams at half: tools/probes/gather_calib.hip); WRITE_SIZE as reported" % factor,
+           "hbm_bytes_per_launch": int(factor * fetch_kb * 1024 + write_kb * 1024), "launch_ms_under_profiler": ms, "build": build_identity()}
     json.dump(hbm, open(os.path.join(out_dir, "hbm_traffic.json"), "w"), indent=1)
     print("hbm_traffic.json:", hbm["hbm_bytes_per_launch"] / 1e9, "GB per launch")
 
@@ -94,7 +104,7 @@ def profile_of(kern):
         if not cycles and ms:
             cycles = ms * 1e-3 * 2.4e9
         wave_quads = c["SQ_WAVE_CYCLES"]
-        prof = {"command": command, "kernel": kern, "workload": key, "launch_ms_under_profiler": ms, "shader_cycles_per_launch": cycles,
+        prof = {"command": command, "kernel": kern, "workload": key, "build": build_identity(), "launch_ms_under_profiler": ms, "shader_cycles_per_launch": cycles,
                 "effective_clock_ghz": (cycles / (ms * 1e-3) / 1e9) if ms else None, "raw": c}
         frac = lambda x: (c[x] / wave_quads) if x in c else None
         prof["wave_cycle_split"] = {"waiting_on_memory_or_barrier (SQ_WAIT_ANY)": frac("SQ_WAIT_ANY"),
