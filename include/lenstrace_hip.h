@@ -97,7 +97,12 @@ enum {
    *   amplify into a flipped ray decision in ~0.03 % of pixels.
    * PORTABLE and STRICT exclude each other. */
   LT_RENDER_FLAG_PORTABLE_MATH = 8u,
-  LT_RENDER_FLAG_STRICT_MATH = 16u
+  LT_RENDER_FLAG_STRICT_MATH = 16u,
+  /* The first accumulator / basic_lighting call of a (scene, image geometry, frames per launch) runs its launch once per
+   * shadow-ray walk (4-5 extra launches inside that call, a host-side wait for their times, all of it counted in that call's
+   * kernel_ms / kernel_launches) and keeps the fastest.  With this flag a call that has no verdict yet times nothing: it uses
+   * the scene's most recent verdict for the program, or any-hit packets.  Pixels do not depend on the walk. */
+  LT_RENDER_FLAG_NO_WALK_TIMING = 32u
 };
 
 typedef struct lt_hip_render_desc {

@@ -19,6 +19,7 @@ RENDER_FLAG_PIXEL_COUNTERS = 2
 RENDER_FLAG_DEVICE_LIBM = 4      # ignored (ABI 2 name of RENDER_FLAG_STRICT_MATH)
 RENDER_FLAG_PORTABLE_MATH = 8
 RENDER_FLAG_STRICT_MATH = 16
+RENDER_FLAG_NO_WALK_TIMING = 32
 
 # every symbol include/lenstrace_hip.h declares
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",

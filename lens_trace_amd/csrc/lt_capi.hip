@@ -158,6 +158,17 @@ __global__ void lt_running_mean_kernel(const float* __restrict__ samples, uint32
   out[i] = acc;
 }
 
+// The walks' slab tests compare against the smallest positive float (`tExit >= max(tEnter, 0x00000001)`: "tExit > 0" in one
+// instruction) and their conservative tests carry a 2^-140 margin: both need float32 denormals to be KEPT, which is hipcc's
+// default for gfx950 and what this library and its run-time compiled user programs are built with.  A build with
+// -fgpu-flush-denormals-to-zero would flush the constant to 0 and accept leaves the reference rejects; lt_hip_create runs this
+// once and refuses such a build instead.
+__global__ void lt_denormal_probe_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+  const float tiny = __uint_as_float(in[0]);                       // 0x00000001
+  out[0] = __float_as_uint(__builtin_fmaxf(tiny, in[1] ? 1.0f : 0.0f));   // max(denormal, 0): the denormal, unless it was flushed
+  out[1] = __float_as_uint(tiny + tiny);                           // 0x00000002
+}
+
 // ---------------------------------------------------------------------------------- context
 struct lt_hip_context {
   int device = -1;
@@ -189,7 +200,7 @@ struct lt_hip_context {
   int shadow_mode[6] = {-1, -1, -1, -1, -1, -1};   // per built-in program: shadow rays as any-hit packets (1) or per lane (0); -1 = not timed yet
   hipEvent_t cal_ev[12] = {};
   std::map<std::vector<uint32_t>, int> shadow_modes;   // (program, W, H, tile geometry) -> the walk timed faster for it on the resident scene
-  void* d_shadowq = nullptr;         // accumulator's queued shadow rays (shadow mode 3): origin+tmax, direction, (pixel, primitive, frame), hit: 64 bytes per slot
+  void* d_shadowq = nullptr;         // accumulator's queued shadow rays (shadow mode 3): origin+tmax, direction, (pixel, primitive, frame), occluded: 52 bytes per slot
   uint64_t shadowq_slots = 0;
   uint32_t* d_shadowCtl = nullptr;   // ... the trace launch's eight work counters (kQueueStride apart) and, behind them, the queue's length
   float* d_samples = nullptr;        // un-accumulated sample images of a fused multi-sample launch
@@ -260,6 +271,24 @@ extern "C" int lt_hip_create(int device_index, lt_hip_context** out_ctx) {
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc((void**)&ctx->d_stats, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  {   // float32 denormals must be kept (lt_denormal_probe_kernel)
+    const uint32_t in[2] = {1u, 0u};
+    uint32_t out[2] = {0u, 0u};
+    uint32_t* d = (uint32_t*)ctx->d_stats;
+    if ((e = hipMemcpy(d, in, sizeof(in), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+    hipLaunchKernelGGL(lt_denormal_probe_kernel, dim3(1), dim3(1), 0, ctx->stream, (const uint32_t*)d, d + 2);
+    if ((e = hipGetLastError()) != hipSuccess) return bail("kernel launch (is this library built for gfx950?)", e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
+    if ((e = hipMemcpy(out, d + 2, sizeof(out), hipMemcpyDeviceToHost)) != hipSuccess) return bail("hipMemcpy", e);
+    if (out[0] != 1u || out[1] != 2u) {
+      (void)hipFree(ctx->d_stats);
+      (void)hipEventDestroy(ctx->ev0);
+      (void)hipEventDestroy(ctx->ev1);
+      (void)hipStreamDestroy(ctx->stream);
+      delete ctx;
+      return fail(nullptr, LT_ERR_NO_DEVICE, "this build flushes float32 denormals to zero (-fgpu-flush-denormals-to-zero?): the walks' slab tests need them kept");
+    }
+  }
   *out_ctx = ctx;
   return LT_OK;
 }
@@ -548,7 +577,7 @@ extern "C" int lt_hip_own_hierarchy(const void* nodes, uint64_t node_bytes, int 
   }
   if (rank8) {
     std::vector<uint32_t> r;
-    lt_retree::reference_order(nodes, n_prims, r);
+    lt_retree::reference_order(nodes, n_nodes, n_prims, r);
     memcpy(rank8, r.data(), r.size() * sizeof(uint32_t));
   }
   return h;
@@ -698,7 +727,7 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
         ctx->n_wide = groups;
         ctx->wide_height = hw;
         std::vector<uint32_t> rank8;
-        lt_retree::reference_order(nodes, n_prims, rank8);
+        lt_retree::reference_order(nodes, n_nodes, n_prims, rank8);
         LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_rank8, rank8.size() * sizeof(uint32_t)));
         LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_rank8, rank8.data(), rank8.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       }
@@ -763,7 +792,9 @@ static void launch_program(const LaunchConfig& k, dim3 grid, uint32_t lds, hipSt
 #define LT_LAUNCH(D, S, M) hipLaunchKernelGGL((lt_render_kernel<PROGRAM, Config<D, S, M>>), grid, dim3(kBlock), lds, s, sc, fp, out, st, queues)
   // (DEEP -- LDS stack rows beyond kLdsStack spilled to scratch -- concerns the counting kernels only: the others keep no per-lane
   // stack in LDS, whatever the height of the caller's tree)
-  if (k.devlibm == 2) {     // the default flavour: the reference kernels as RendererOpenCL builds them
+  if constexpr (PROGRAM == kAccumulatorQueue) {   // (never a counting launch)
+    if (k.devlibm == 2) LT_LAUNCH(false, false, 2); else if (k.devlibm == 1) LT_LAUNCH(false, false, 1); else LT_LAUNCH(false, false, 0);
+  } else if (k.devlibm == 2) {     // the default flavour: the reference kernels as RendererOpenCL builds them
     if (k.stats) { if (k.deep) LT_LAUNCH(true, true, 2); else LT_LAUNCH(false, true, 2); } else LT_LAUNCH(false, false, 2);
   } else if (k.devlibm == 1) {   // strict build of the reference kernels
     if (k.stats) { if (k.deep) LT_LAUNCH(true, true, 1); else LT_LAUNCH(false, true, 1); } else LT_LAUNCH(false, false, 1);
@@ -863,6 +894,8 @@ static int launch_gi_sample(lt_hip_context* ctx, hipStream_t s, const SceneDev& 
       hipLaunchKernelGGL((lt_gi_classify_kernel<CFG>), streamGrid, streamBlock, 0, s, sc, fp, gp, (uint32_t)d);
       hipLaunchKernelGGL((lt_gi_shadow_kernel<CFG>), streamGrid, streamBlock, 0, s, sc, fp, gp, (uint32_t)d);
       tp.o = gp.so; tp.d = gp.sd; tp.m = gp.sm;
+      tp.occluded = (uint32_t*)ctx->d_gi[11];   // (the extension rays' hits have been read by then: lt_gi_shadow_kernel is behind us in the stream)
+      gp.occluded = tp.occluded;
       tp.count = gp.hitCount + (size_t)d * kQueueStride;
       tp.next = shadowWork + (size_t)d * 8 * kQueueStride;
       tp.dead = 0u;
@@ -1231,6 +1264,8 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
     auto it = ctx->shadow_modes.find(shadowKey);
     shadowMode = it == ctx->shadow_modes.end() ? -1 : it->second;
   }
+  if (shadowMode < 0 && (d->flags & LT_RENDER_FLAG_NO_WALK_TIMING))   // the caller wants no timing launches in this call
+    shadowMode = ctx->shadow_mode[d->program] >= 0 ? ctx->shadow_mode[d->program] : 1;
   if (shadowMode == 3 && d->program != LT_PROGRAM_ACCUMULATOR) shadowMode = 0;   // (queued shadow rays are accumulator's)
   sc.shadowPackets = shadowMode > 0 ? (uint32_t)shadowMode : 0u;
   ctx->mean_pairs = 0;
@@ -1287,7 +1322,10 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
           switch (d->program) {
             case LT_PROGRAM_BASIC: launch_program<kBasic>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
             case LT_PROGRAM_BASIC_LIGHTING: launch_program<kBasicLighting>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
-            case LT_PROGRAM_ACCUMULATOR: launch_program<kAccumulator>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
+            case LT_PROGRAM_ACCUMULATOR:
+              if (sc.shadowPackets == 3u) launch_program<kAccumulatorQueue>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues);
+              else launch_program<kAccumulator>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues);
+              break;
             case LT_PROGRAM_GLOBAL_ILLUMINATION: launch_program<kGI>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
             case LT_PROGRAM_GLOBAL_ILLUMINATION_25: launch_program<kGI25>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
             default: launch_program<kCustom>(lcl, g, lds, s, sc, fpl, out_launch, ctx->d_stats, queues); break;
@@ -1303,7 +1341,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
             if (ctx->d_shadowq) LT_HIP_CHECK(ctx, hipFree(ctx->d_shadowq));
             ctx->d_shadowq = nullptr;
             ctx->shadowq_slots = 0;
-            LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_shadowq, slots * 64));
+            LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_shadowq, slots * 52));   // (origin + tmax, direction, pixel / primitive / frame: 48 bytes; its fate: 4)
             ctx->shadowq_slots = slots;
           }
           if (!ctx->d_shadowCtl) LT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_shadowCtl, 9 * kQueueStride * sizeof(uint32_t)));
@@ -1314,14 +1352,14 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
           launch_render(fpl, g);
           TraceParams tp{};
           tp.o = sc.shadowQueue; tp.d = sc.shadowQueue + sc.shadowCap; tp.m = (const uint4*)(sc.shadowQueue + 2 * (size_t)sc.shadowCap);
-          tp.hit = (uint4*)(sc.shadowQueue + 3 * (size_t)sc.shadowCap);
+          tp.occluded = (uint32_t*)(sc.shadowQueue + 3 * (size_t)sc.shadowCap);
           tp.count = ctx->d_shadowCtl + 8 * kQueueStride;
           tp.next = ctx->d_shadowCtl;
           const char* re = getenv("LT_TRACE_REFILL");
           tp.refill = re ? (uint32_t)std::max(1, std::min(64, atoi(re))) : 24u;
           tp.dead = 1u;
           hipLaunchKernelGGL((lt_trace_kernel<kGI, true>), dim3(resident), dim3(kBlock), (uint32_t)((kTraceRows + kTraceStage) * kBlock * sizeof(int)), s, sc, tp);
-          hipLaunchKernelGGL(lt_shadow_resolve_kernel, dim3((uint32_t)ctx->cu_count * 8u), dim3(256), 0, s, tp.m, (const uint4*)tp.hit, (uint32_t)slots, out_launch,
+          hipLaunchKernelGGL(lt_shadow_resolve_kernel, dim3((uint32_t)ctx->cu_count * 8u), dim3(256), 0, s, tp.m, (const uint32_t*)tp.occluded, (uint32_t)slots, out_launch,
                              fpl.frameStride, fpl.depth);
           LT_HIP_CHECK(ctx, hipGetLastError());
           launches += 2;

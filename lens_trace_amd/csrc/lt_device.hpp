@@ -45,6 +45,8 @@ constexpr float kFltMax = 3.402823466e+38f;
 constexpr uint32_t kDeadSlot = 0xffffffffu;   // first word of the third array of a direct-mapped ray queue's slot that holds no ray
 
 enum Program { kBasic = 0, kBasicLighting = 1, kAccumulator = 2, kGI = 3, kGI25 = 4, kCustom = 5,
+               kAccumulatorQueue = 7,   // accumulator whose shadow rays are not walked but queued for lt_trace_kernel (SceneDev::shadowPackets
+                                        // == 3): an instantiation of its own, so that the others carry none of the queue's code or registers
                kGIPrimary = 6,   // the global-illumination programs' camera-ray stage (lt_gi_primary_kernel): kGI's arithmetic; its shadow
                                  // rays start on camera hits, as coherent as accumulator's, and may walk as any-hit packets
                kUser = 1000 };
@@ -1139,14 +1141,14 @@ __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, fl
   V3 out{0.0f, 0.0f, 0.0f};
   Hit pl{0, 0, kFltMax, 0.0f, 0.0f};
   traverse_camera<PROGRAM, CFG::kDeep, CFG::kStats>(sc, cameraRay, pl, st, c);
-  if (PROGRAM == kAccumulator) {
+  if (PROGRAM == kAccumulator || PROGRAM == kAccumulatorQueue) {
     if (is_light(sc.lights, pl.prim)) return V3{1.0f, 1.0f, 1.0f};
   }
   if (pl.hitType == 1) {
     const float* pr = prim_ptr(sc, pl.prim);
     V4 position, normal;
     float ndotl;
-    if (PROGRAM == kAccumulator && !CFG::kStats && sc.shadowPackets == 3u) {
+    if constexpr (PROGRAM == kAccumulatorQueue) {
       // the shadow ray goes into the queue (lt_trace_kernel walks it); the colour is the unoccluded sample's until
       // lt_shadow_resolve_kernel has looked at the ray's fate
       V4 toLight;
@@ -1158,10 +1160,11 @@ __device__ inline V3 shade_lighting(const SceneDev& sc, const Ray& cameraRay, fl
       queued = true;
       const Material* m = sc.mats + prim_material(pr);
       out = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
-    } else if (direct_light<PROGRAM, CFG>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u),
-                                           0.0f, position, normal, ndotl, st, c)) {
-      const Material* m = sc.mats + prim_material(pr);
-      out = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
+    } else {
+      if (direct_light<PROGRAM, CFG>(sc, pr, pl.prim, pl.u, pl.v, fx, fy, (float)s, (float)(s + 1u), (float)(s + 2u), 0.0f, position, normal, ndotl, st, c)) {
+        const Material* m = sc.mats + prim_material(pr);
+        out = V3{m->diffuse[0] * ndotl, m->diffuse[1] * ndotl, m->diffuse[2] * ndotl};
+      }
     }
   }
   return out;
@@ -1323,8 +1326,8 @@ __device__ inline V3 shade_pixel(const SceneDev& sc, const FrameParams& fp, uint
   } else if (PROGRAM == kUser) {
     color = user_shade<CFG>(sc, ray, fx, fy, frameCount, st, c);
 #endif
-  } else if (PROGRAM == kAccumulator) {
-    color = shade_lighting<kAccumulator, CFG>(sc, ray, fx, fy, frameCount, st, c, qslot, qpixel, qframe, queued);
+  } else if (PROGRAM == kAccumulator || PROGRAM == kAccumulatorQueue) {
+    color = shade_lighting<PROGRAM, CFG>(sc, ray, fx, fy, frameCount, st, c, qslot, qpixel, qframe, queued);
   } else if (PROGRAM == kGI) {
     color = shade_gi<CFG>(sc, ray, fx, fy, frameCount, fp.giMaxDepth, st, c);
   } else {

@@ -31,7 +31,7 @@ __device__ __forceinline__ void render_square(const SceneDev& sc, const FramePar
   const uint32_t ly = sby * 8u + (lane >> 3);
   const uint32_t x = tx * fp.tileW + lx, y = ty * fp.tileH + ly;
   const bool valid = k < fp.tilesInCall && lx < fp.tileW && ly < fp.tileH && x < fp.width && y < fp.height;
-  const bool queueing = PROGRAM == kAccumulator && !STATS && sc.shadowPackets == 3u;
+  constexpr bool queueing = PROGRAM == kAccumulatorQueue;
   const uint32_t qslot = (pos * fp.fusedFrames + frame) * (uint32_t)kBlock + lane;
   bool queued = false;
   if (valid) {
@@ -192,7 +192,7 @@ struct GiParams {
   const uint4* hits;
   // ... and then the stage runs as three kernels with a compacted list between them instead of one (below): the paths whose
   // extension ray hit a surface (hitList, hitCount), their light samples and shadow rays (so = position + tmax, sd = direction,
-  // sm = (path, primitive, n.l), sn = normal), which lt_trace_kernel walks as any-hit rays (occluded: hits[i].y of the LIST entry).
+  // sm = (path, primitive, n.l), sn = normal), which lt_trace_kernel walks as any-hit rays (their fate: `occluded`, by list entry).
   // Queue 0 is then not appended to but DIRECT-MAPPED: the path of lane l of square p (position in the XCD-contiguous square
   // list) and frame f sits at slot (p * frames + f) * 64 + l, dead slots (no surface hit, pixel outside the image) marked by
   // m.x = kDeadPath.  No atomic in the camera stage (its 2 M appends to one counter were a 12 ns queue of their own), and the
@@ -201,6 +201,7 @@ struct GiParams {
   uint32_t* hitList;
   uint32_t* hitCount;      // [maxDepth + 1], kQueueStride dwords apart
   float4* so; float4* sd; uint4* sm; float4* sn;
+  const uint32_t* occluded;   // [i of the list] != 0: the shadow ray met something
 };
 
 __device__ __forceinline__ bool square_pixel(const FrameParams& fp, uint32_t b, uint32_t& x, uint32_t& y, uint32_t& pix) {
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void lt_gi_finish_kernel(SceneDev sc, FramePar
     float4 so = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sn = so;
     uint4 sm = make_uint4(0u, 0u, 0u, 0u), misc = sm;
     float fx = 0.0f;
-    if (i < total && gp.hits[i].y == 0u) {   // the shadow ray found nothing (gi.cl:351)
+    if (i < total && gp.occluded[i] == 0u) {   // the shadow ray found nothing (gi.cl:351)
       so = gp.so[i]; sn = gp.sn[i]; sm = gp.sm[i];
       const uint32_t e = sm.x;
       misc = in.m[e];
@@ -527,7 +528,8 @@ __global__ __launch_bounds__(256) void lt_gi_finish_kernel(SceneDev sc, FramePar
 // of the shading that produced the ray or will consume the hit: that is why this is a kernel of its own.
 //   rays:   o[i] = (origin.xyz, tmax of an any-hit ray), d[i] = direction.xyzw, m[i].y = the primitive the ray starts on (ignored,
 //           acc.cl:188)
-//   result: hit[i] = (primitive, hitType, u, v)    (t is not kept: no caller reads it; an any-hit ray's caller reads hitType only)
+//   result: hit[i] = (primitive, hitType, u, v) of a closest-hit ray (t is not kept: no caller reads it); occluded[i] = hitType of an
+//           any-hit ray (its caller reads nothing else)
 // Rays the walks over the own tree do not take (a non-finite component, magnitudes beyond packet_ray_ok) are walked at once, in
 // the reference's order over the caller's tree, by the lane that drew them.  Every wave reaches the exit: the queue hands out
 // each index once, a lane's walk ends (the stack only holds entries of a finite tree), and the loop ends when the queue is drained
@@ -537,7 +539,8 @@ struct TraceParams {
   const float4* o;
   const float4* d;
   const uint4* m;
-  uint4* hit;
+  uint4* hit;              // closest-hit walks
+  uint32_t* occluded;      // any-hit walks: one word per ray, != 0 when something was hit (their callers read nothing else)
   const uint32_t* count;   // rays in the queue (device memory: written by the stage that filled it)
   uint32_t* next;          // work counters (zeroed by the host): one per eighth of the queue, kQueueStride dwords apart
   uint32_t refill;         // idle lanes that trigger a refill
@@ -638,7 +641,8 @@ __global__ __launch_bounds__(kBlock, 8) void lt_trace_kernel(SceneDev sc, TraceP
           ScratchStack ss;
           Counters c{};
           traverse_nodes_impl<PROGRAM, ScratchStack, false, false, ANYHIT, false>(sc, ray, ix, iy, iz, true, ign, pl, ss, c);
-          tp.hit[idx] = make_uint4((uint32_t)pl.prim, (uint32_t)pl.hitType, __float_as_uint(pl.u), __float_as_uint(pl.v));
+          if (ANYHIT) tp.occluded[idx] = (uint32_t)pl.hitType;
+          else tp.hit[idx] = make_uint4((uint32_t)pl.prim, (uint32_t)pl.hitType, __float_as_uint(pl.u), __float_as_uint(pl.v));
         }
       }
       stageTaken += take;
@@ -649,7 +653,8 @@ __global__ __launch_bounds__(kBlock, 8) void lt_trace_kernel(SceneDev sc, TraceP
     }
     if (active) {
       if (own_walk_step<PROGRAM, ANYHIT, kTraceRows>(sc, ray, ix, iy, iz, w, pl, col, deep, e, sp)) {
-        tp.hit[idx] = make_uint4((uint32_t)pl.prim, (uint32_t)pl.hitType, __float_as_uint(pl.u), __float_as_uint(pl.v));
+        if (ANYHIT) tp.occluded[idx] = (uint32_t)pl.hitType;
+        else tp.hit[idx] = make_uint4((uint32_t)pl.prim, (uint32_t)pl.hitType, __float_as_uint(pl.u), __float_as_uint(pl.v));
         active = false;
       }
     }
@@ -658,12 +663,12 @@ __global__ __launch_bounds__(kBlock, 8) void lt_trace_kernel(SceneDev sc, TraceP
 
 // accumulator's shadow rays walked by lt_trace_kernel (SceneDev::shadowPackets == 3): a sample whose ray met an occluder is
 // black (acc.cl:276-279: the colour is only assigned when the shadow payload's hitType is 0)
-__global__ __launch_bounds__(256) void lt_shadow_resolve_kernel(const uint4* __restrict__ m, const uint4* __restrict__ hit, uint32_t slots, float* __restrict__ out,
-                                                                unsigned long long frameStride, uint32_t depth) {
+__global__ __launch_bounds__(256) void lt_shadow_resolve_kernel(const uint4* __restrict__ m, const uint32_t* __restrict__ occluded, uint32_t slots,
+                                                                float* __restrict__ out, unsigned long long frameStride, uint32_t depth) {
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += stride) {
     const uint4 mm = m[i];
-    if (mm.x == kDeadSlot || hit[i].y == 0u) continue;
+    if (mm.x == kDeadSlot || occluded[i] == 0u) continue;
     float* o = out + (size_t)mm.z * frameStride + (size_t)mm.x * depth;
     o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
   }

@@ -367,38 +367,38 @@ inline int collapse_wide(const std::vector<Node>& own, uint32_t n_prims, std::ve
 // rank8[8 * primitive + octant]: position of the primitive's (first) leaf in the caller's tree walked depth-first, near child
 // first, by a ray whose direction signs are `octant` (bit a = component a negative: the reference's dirIsNeg[node->axis],
 // acc.cl:150-160).  0xffffffff for primitives no leaf refers to.
-inline void reference_order(const void* nodes, uint32_t n_prims, std::vector<uint32_t>& rank8) {
+// In closed form: a leaf's position is the number of leaves the walk meets before it -- for every ancestor whose FAR child (for
+// that octant) the leaf lies under, the leaves under the near child.  The tree is in pre-order (children behind their parent), so
+// one backward pass counts the leaves under every node and one forward pass hands every node the eight positions of its first
+// leaf: no walks, no threads.  (Nodes the root does not reach keep no position, as in a walk.)
+inline void reference_order(const void* nodes, uint32_t n_nodes, uint32_t n_prims, std::vector<uint32_t>& rank8) {
   const Node* nd = reinterpret_cast<const Node*>(nodes);
   rank8.assign(8 * (size_t)n_prims, 0xffffffffu);
-  auto one = [&](uint32_t octant) {
-    std::vector<uint32_t> stack{0u};
-    uint32_t next = 0;
-    while (!stack.empty()) {
-      const uint32_t i = stack.back();
-      stack.pop_back();
-      const Node& p = nd[i];
-      if (p.cnt != 0) {
-        uint32_t& r = rank8[8 * (size_t)(uint32_t)p.off + octant];
-        if (r == 0xffffffffu) r = next;
-        next++;
-        continue;
-      }
-      const bool neg = ((octant >> p.axis) & 1u) != 0u;
-      stack.push_back(neg ? i + 1 : (uint32_t)p.off);   // far child, visited second
-      stack.push_back(neg ? (uint32_t)p.off : i + 1);   // near child
+  if (n_nodes == 0) return;
+  std::vector<uint32_t> leaves(n_nodes);
+  for (uint32_t i = n_nodes; i-- > 0;) leaves[i] = nd[i].cnt != 0 ? 1u : leaves[i + 1] + leaves[(uint32_t)nd[i].off];
+  struct Base { uint32_t r[8]; };
+  std::vector<Base> base(n_nodes);
+  std::vector<uint8_t> reached(n_nodes, 0);
+  for (int o = 0; o < 8; o++) base[0].r[o] = 0u;
+  reached[0] = 1;
+  for (uint32_t i = 0; i < n_nodes; i++) {
+    if (!reached[i]) continue;
+    const Node& p = nd[i];
+    if (p.cnt != 0) {
+      uint32_t* r = &rank8[8 * (size_t)(uint32_t)p.off];
+      for (int o = 0; o < 8; o++)
+        if (base[i].r[o] < r[o]) r[o] = base[i].r[o];   // (two leaves on one primitive: the first one the walk meets)
+      continue;
     }
-  };
-  // eight writers, eight disjoint sets of words; small trees, and octants no thread could be had for, on this thread
-  std::vector<std::thread> pool;
-  uint32_t o = 0;
-  if (n_prims >= 50000u && available_cpus() > 1) {
-    try {
-      for (; o < 7; o++) pool.emplace_back(one, o);
-    } catch (...) {
+    const uint32_t left = i + 1, right = (uint32_t)p.off;
+    for (int o = 0; o < 8; o++) {
+      const bool neg = ((o >> p.axis) & 1) != 0;   // the right child is the near one
+      base[left].r[o] = base[i].r[o] + (neg ? leaves[right] : 0u);
+      base[right].r[o] = base[i].r[o] + (neg ? 0u : leaves[left]);
     }
+    reached[left] = reached[right] = 1;
   }
-  for (; o < 8; o++) one(o);
-  for (std::thread& th : pool) th.join();
 }
 
 }  // namespace lt_retree

@@ -86,10 +86,14 @@ def test_bench_roofline_is_a_fraction_of_a_stated_peak():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     key = "synthetic height-field wall, 1002530 triangles, 3840x2160, accumulator"
-    prof = bench._latest_profile("issue_profile.json", key)
+    prof, why = bench._latest_profile("issue_profile.json", key)
     if prof is None:
+        # counters of another build of the kernels say nothing about this one: the line then claims nothing and says why
+        r = bench.roofline(key, "lt_render_kernel<accumulator>", 17.0, 1.0, 16, 1.38e12, True)
+        assert r["frac"] is None and ("note" not in r or "stale" in r["note"]), r
         import pytest
-        pytest.skip("no issue_profile.json for the headline workload committed yet")
+        pytest.skip("no issue_profile.json of this build for the headline workload committed: " + str(why))
+    assert prof["build"]["csrc_sha256"] == bench.build_identity()["csrc_sha256"]
     launch_ms = prof["launch_ms_under_profiler"]
     r = bench.roofline(key, "lt_render_kernel<accumulator>", launch_ms, 1.0, 16, 1.38e12, True)
     assert r["bound"] in ("valu-issue", "scalar-issue") and 0.0 < r["frac"] <= 1.0

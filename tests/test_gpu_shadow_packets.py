@@ -102,3 +102,27 @@ def test_the_walk_is_timed_once_per_scene_program_and_image_geometry(monkeypatch
     out2, st = once(PATHS["accumulator"], frameFirst=1, frameCount=4, accumulate=True)
     assert st["kernel_launches"] == own(st["shadow_packets"]) and np.array_equal(out, out2)
     r.close()
+
+
+def test_a_call_can_decline_the_timing_launches(monkeypatch):
+    """LT_RENDER_FLAG_NO_WALK_TIMING: a first call of a geometry with the flag runs its own launch only, with the scene's most
+    recent verdict for the program or any-hit packets; the pixels are the same."""
+    from lens_trace_amd import _capi as C
+    from lens_trace_amd.renderer import make_desc
+    import torch
+    monkeypatch.delenv("LT_SHADOW_PACKETS", raising=False)
+    r = RendererHIP(0)
+    scene = synth.heightfield_wall(48).validate()
+    r.set_scene(scene)
+    W, H = 160, 96
+    cam = sc.camera_with_frame(scene.camera, 1)
+    want = po.render(scene, cam, W, H, po.ACCUMULATOR)
+    d = make_desc(C.PROGRAM_ACCUMULATOR, W, H, 3, cam, portable_math=True)
+    d.flags |= C.RENDER_FLAG_NO_WALK_TIMING
+    buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    r.render_device(d, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = r.stats()
+    assert st["kernel_launches"] == 1 and st["shadow_packets"] == 1
+    assert np.array_equal(buf.cpu().numpy(), want)
+    r.close()
