@@ -170,6 +170,11 @@ __global__ void lt_denormal_probe_kernel(const uint32_t* __restrict__ in, uint32
 }
 
 // ---------------------------------------------------------------------------------- context
+struct SceneHash {
+  uint64_t buf[4] = {0, 0, 0, 0};   // nodes, primitives, materials, lights
+  bool operator==(const SceneHash& o) const { return memcmp(buf, o.buf, sizeof(buf)) == 0; }
+};
+
 struct lt_hip_context {
   int device = -1;
   std::string err;
@@ -187,7 +192,8 @@ struct lt_hip_context {
   uint32_t n_nodes = 0, n_prims = 0, n_mats = 0;
   int bvh_height = 0;
   bool has_scene = false;
-  uint64_t scene_hash = 0, scene_sizes[4] = {0, 0, 0, 0};   // content hash + sizes of the resident scene (lt_hip_set_scene)
+  SceneHash scene_hash{};                                    // content hashes (one per buffer) ...
+  uint64_t scene_sizes[4] = {0, 0, 0, 0};                   // ... and sizes of the resident scene (lt_hip_set_scene)
   uint32_t scene_uploads = 0, scene_reused = 0;
   float* d_out = nullptr;            // staging output for lt_hip_render
   uint64_t d_out_bytes = 0;
@@ -530,12 +536,12 @@ static uint64_t hash_piece(const uint8_t* b, uint64_t n, uint64_t seed) {
 
 // The four scene buffers as one list of pieces, hashed by up to host_threads() threads (fewer when threads cannot be had: the
 // pieces left are hashed by this one).
-static uint64_t hash_scene(const void* const bufs[4], const uint64_t sizes[4]) {
+static SceneHash hash_scene(const void* const bufs[4], const uint64_t sizes[4]) {
   constexpr uint64_t kPiece = 4ull << 20;
-  struct Piece { const uint8_t* p; uint64_t n; };
+  struct Piece { const uint8_t* p; uint64_t n; int of; };
   std::vector<Piece> pieces;
   for (int k = 0; k < 4; k++)
-    for (uint64_t off = 0; off < sizes[k]; off += kPiece) pieces.push_back({(const uint8_t*)bufs[k] + off, std::min(kPiece, sizes[k] - off)});
+    for (uint64_t off = 0; off < sizes[k]; off += kPiece) pieces.push_back({(const uint8_t*)bufs[k] + off, std::min(kPiece, sizes[k] - off), k});
   std::vector<uint64_t> hashes(pieces.size());
   std::atomic<size_t> next{0};
   auto work = [&]() {
@@ -549,10 +555,12 @@ static uint64_t hash_scene(const void* const bufs[4], const uint64_t sizes[4]) {
   }
   work();
   for (std::thread& th : pool) th.join();
-  uint64_t r = 0x243F6A8885A308D3ull;
-  for (uint64_t h : hashes) {
-    r = (r ^ h) * 0x9E3779B97F4A7C15ull;
-    r ^= r >> 29;
+  SceneHash r;
+  for (int k = 0; k < 4; k++) r.buf[k] = 0x243F6A8885A308D3ull + (uint64_t)k;
+  for (size_t i = 0; i < pieces.size(); i++) {
+    uint64_t& b = r.buf[pieces[i].of];
+    b = (b ^ hashes[i]) * 0x9E3779B97F4A7C15ull;
+    b ^= b >> 29;
   }
   return r;
 }
@@ -612,7 +620,7 @@ extern "C" int lt_hip_own_wide(const void* own_nodes, uint64_t node_bytes, uint3
 }
 
 static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims, uint64_t prim_bytes, const void* materials,
-                          uint64_t material_bytes, const void* lights, uint64_t light_bytes, const uint64_t* known_hash);
+                          uint64_t material_bytes, const void* lights, uint64_t light_bytes, const SceneHash* known_hash);
 
 extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims,
                                 uint64_t prim_bytes, const void* materials, uint64_t material_bytes, const void* lights,
@@ -625,7 +633,7 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
 }
 
 static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims, uint64_t prim_bytes, const void* materials,
-                          uint64_t material_bytes, const void* lights, uint64_t light_bytes, const uint64_t* known_hash) {
+                          uint64_t material_bytes, const void* lights, uint64_t light_bytes, const SceneHash* known_hash) {
   if (!ctx) return LT_ERR_INVALID_ARGUMENT;
   if (!nodes || !prims || !materials || !lights) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "NULL scene buffer");
   if (node_bytes == 0 || node_bytes % 32 || prim_bytes == 0 || prim_bytes % 76 || material_bytes == 0 || material_bytes % 32 ||
@@ -638,10 +646,57 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
   // material is honoured).  LT_SCENE_ALWAYS_UPLOAD=1 turns the shortcut off.
   const uint64_t sizes[4] = {node_bytes, prim_bytes, material_bytes, light_bytes};
   const void* const bufs[4] = {nodes, prims, materials, lights};
-  const uint64_t hash = known_hash ? *known_hash : hash_scene(bufs, sizes);
-  if (ctx->has_scene && hash == ctx->scene_hash && memcmp(sizes, ctx->scene_sizes, sizeof(sizes)) == 0 && !getenv("LT_SCENE_ALWAYS_UPLOAD")) {
-    ctx->scene_reused++;
-    return LT_OK;
+  const SceneHash hash = known_hash ? *known_hash : hash_scene(bufs, sizes);
+  if (ctx->has_scene && memcmp(sizes, ctx->scene_sizes, sizeof(sizes)) == 0 && !getenv("LT_SCENE_ALWAYS_UPLOAD")) {
+    if (hash == ctx->scene_hash) {
+      ctx->scene_reused++;
+      return LT_OK;
+    }
+    // An edit that left the nodes alone -- a material, a light, a primitive's normals or material index -- leaves the hierarchies
+    // alone too: the buffers that changed are uploaded, and what is derived from the primitives (traversal triangles, the leaf
+    // records of both walks) is made again by the kernels that made it: no host-side build, no second copy of the tree.
+    if (hash.buf[0] == ctx->scene_hash.buf[0]) {
+      const bool primsChanged = hash.buf[1] != ctx->scene_hash.buf[1];
+      std::string why;
+      if (primsChanged) {
+        for (uint32_t i = 0; i < n_prims && why.empty(); i++) {
+          int32_t m;
+          memcpy(&m, (const uint8_t*)prims + 76 * (size_t)i + 72, 4);
+          if (m < 0 || (uint32_t)m >= n_mats) why = "materialIndex out of range";
+        }
+      }
+      uint32_t lc;
+      memcpy(&lc, lights, 4);
+      if (lc > 64) why = "more than 64 emissive triangles";
+      for (uint32_t i = 0; i < lc && i < 64 && why.empty(); i++) {
+        uint32_t pi;
+        memcpy(&pi, (const uint8_t*)lights + 4 + 4 * i, 4);
+        if (pi >= n_prims) why = "light primitive out of range";
+      }
+      if (!why.empty()) return fail(ctx, LT_ERR_BAD_SCENE, why);
+      LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+      LT_HIP_CHECK(ctx, hipDeviceSynchronize());   // (nothing of an earlier call may still be reading what is about to change)
+      if (primsChanged) {
+        LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_prims, prims, prim_bytes, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(lt_retile_kernel, dim3((n_prims + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->d_prims, (float4*)ctx->d_tris, n_prims);
+        if (ctx->d_nodes2 && ctx->d_pairs2 && ctx->d_wide) {
+          const uint32_t n2 = ctx->n_nodes2;
+          hipLaunchKernelGGL(lt_own_pair_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2, (const float*)ctx->d_prims,
+                             (float4*)ctx->d_pairs2, n2);
+          hipLaunchKernelGGL(lt_wide_leaf_kernel, dim3((n2 + 1 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2, (const float*)ctx->d_prims,
+                             (float4*)((uint4*)ctx->d_wide + 4), n2, ctx->n_wide, n_prims);
+        }
+        LT_HIP_CHECK(ctx, hipGetLastError());
+      }
+      LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_mats, materials, material_bytes, hipMemcpyHostToDevice));
+      LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_lights, lights, light_bytes, hipMemcpyHostToDevice));
+      LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->scene_hash = hash;
+      ctx->scene_uploads++;
+      for (int& m : ctx->shadow_mode) m = -1;   // (other lights: other shadow rays)
+      ctx->shadow_modes.clear();
+      return LT_OK;
+    }
   }
   std::string msg;
   const int height = validate_scene((const uint8_t*)nodes, n_nodes, (const uint8_t*)prims, n_prims, n_mats, (const uint8_t*)lights, msg);
@@ -684,7 +739,7 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
       hipLaunchKernelGGL(lt_own_pair_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2,
                          (const float*)ctx->d_prims, (float4*)ctx->d_pairs2, n2);
       LT_HIP_CHECK(ctx, hipGetLastError());
-      // ... and the per-lane walks' 4-wide groups and leaf records, made from the same upload of the tree; the 32-byte form is not kept
+      // ... and the per-lane walks' 4-wide groups and leaf records, made from the same upload of the tree
       std::vector<uint32_t> children, groupOf;
       const int hw = lt_retree::collapse_wide(own, n_prims, children, groupOf);
       const uint32_t groups = (uint32_t)(children.size() / 4);
@@ -717,11 +772,9 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
         (void)hipFree(d_groupOf);
         ownOk = bad == 0;   // (a bound off the grid cannot happen for a grid sized from the root's box)
       }
-      LT_HIP_CHECK(ctx, hipFree(ctx->d_nodes2));
-      ctx->d_nodes2 = nullptr;
       if (!ownOk) {   // the scene then walks the caller's tree
-        for (void** p : {&ctx->d_pairs2, &ctx->d_wide}) { if (*p) (void)hipFree(*p); *p = nullptr; }
-      } else {
+        for (void** p : {&ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_wide}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+      } else {   // (the own tree's 32-byte form stays resident: an edit of the primitives alone re-makes the leaf records from it)
         ctx->n_nodes2 = n2;
         ctx->height2 = h2;
         ctx->n_wide = groups;
@@ -1586,7 +1639,7 @@ extern "C" int lt_hip_render_scene(lt_hip_context* ctx, const void* nodes, uint6
     if (speculate) {
       rc = render_to_host(ctx, desc, out_host, out_bytes, need, staged);
       if (rc) return rc;
-      const uint64_t hash = hash_scene(bufs, sizes);   // (while the GPU renders)
+      const SceneHash hash = hash_scene(bufs, sizes);   // (while the GPU renders)
       rc = finish_readback(ctx, need, out_host, staged);
       if (rc) return rc;
       if (hash == ctx->scene_hash) {

@@ -44,7 +44,10 @@ struct Node {   // LinearBVHNode (include/lens_trace/acceleration_structure_expl
 };
 static_assert(sizeof(Node) == 32, "LinearBVHNode is 32 bytes");
 
-constexpr int kBins = 32;
+#ifndef LT_RETREE_BINS
+#define LT_RETREE_BINS 32
+#endif
+constexpr int kBins = LT_RETREE_BINS;
 
 // CPUs this process may run on (its affinity mask: a container's share, not the machine's core count)
 inline int available_cpus() {

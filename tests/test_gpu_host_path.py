@@ -61,3 +61,56 @@ def test_scene_handed_over_with_every_frame_is_hashed_behind_the_frame_and_edits
     whole, _ = frame(frameFirst=1, frameCount=4, accumulate=True)
     assert np.array_equal(cont, whole)
     r.close()
+
+
+def test_edits_that_leave_the_nodes_alone_keep_the_hierarchies(monkeypatch):
+    """A material, a light list or the primitives edited in place (same sizes, nodes untouched): the changed buffers are uploaded
+    and the leaf records re-made on the device -- no host-side build (own_tree_ms keeps the value of the one build) -- and the
+    frame equals the oracle's on the edited scene, through the packet walks, the per-lane walks and the queued shadow rays."""
+    from lens_trace_amd import synth
+    s = synth.heightfield_wall(40).validate()
+    cam = sc.camera_with_frame(s.camera, 3)
+    W, H = 160, 96
+    r = RendererHIP(0)
+
+    def frame():
+        out = np.full((H, W, 3), np.nan, dtype=np.float32)
+        r.render(Props(ACC, (W, H, 3), out, s, pCamera=cam))
+        return out, r.stats()
+
+    for mode in ("1", "0", "3"):
+        monkeypatch.setenv("LT_SHADOW_PACKETS", mode)
+        out, st = frame()
+        built = st["own_tree_ms"]
+        uploads = st["scene_uploads"]
+        assert np.array_equal(out, po.render(s, cam, W, H, po.ACCUMULATOR)) and st["own_tree_height"] > 0
+        prims = s.prims.view(sc.PRIM_DTYPE)
+        keep = prims.copy()
+        # primitives: flip the normals of a third of the wall and move a vertex of every 7th triangle (inside its leaf's box or
+        # not: the box is the caller's business, the triangle test is the reference's on the new vertices)
+        prims["normalA"][::3] *= -1.0
+        prims["normalB"][::3] *= -1.0
+        prims["normalC"][::3] *= -1.0
+        prims["positionB"][::7, 2] -= 0.01
+        out, st = frame()
+        assert st["scene_uploads"] == uploads + 1 and st["own_tree_ms"] == built
+        assert np.array_equal(out, po.render(s, cam, W, H, po.ACCUMULATOR))
+        mats = s.materials.view(sc.MATERIAL_DTYPE)
+        mats["diffuse"][:] = mats["diffuse"][:, ::-1]
+        out, st = frame()
+        assert st["scene_uploads"] == uploads + 2 and st["own_tree_ms"] == built
+        assert np.array_equal(out, po.render(s, cam, W, H, po.ACCUMULATOR))
+        prims[:] = keep
+        out, st = frame()
+        assert st["scene_uploads"] == uploads + 3 and np.array_equal(out, po.render(s, cam, W, H, po.ACCUMULATOR))
+        # a node edited in place is another matter: everything is built again
+        nodes = s.nodes.view(sc.NODE_DTYPE)
+        leaf = int(np.flatnonzero(nodes["primitiveCount"] != 0)[5])
+        saved = nodes["boundsMax"][leaf].copy()
+        nodes["boundsMax"][leaf] = nodes["boundsMin"][leaf]            # the leaf's box shrinks to a point: its triangle is missed as the reference misses it
+        out, st = frame()
+        assert st["scene_uploads"] == uploads + 4 and np.array_equal(out, po.render(s, cam, W, H, po.ACCUMULATOR))
+        nodes["boundsMax"][leaf] = saved
+        out, st = frame()
+        assert np.array_equal(out, po.render(s, cam, W, H, po.ACCUMULATOR))
+    r.close()
