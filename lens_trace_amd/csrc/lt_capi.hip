@@ -698,8 +698,17 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
       return LT_OK;
     }
   }
+  const bool timing = getenv("LT_DEBUG_SCENE_TIMING") != nullptr;
+  auto tmark = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[lt set_scene] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tmark).count());
+    tmark = now;
+  };
   std::string msg;
   const int height = validate_scene((const uint8_t*)nodes, n_nodes, (const uint8_t*)prims, n_prims, n_mats, (const uint8_t*)lights, msg);
+  lap("validate");
   if (height < 0) return fail(ctx, LT_ERR_BAD_SCENE, msg);
   if (height > kMaxStack) return fail(ctx, LT_ERR_BAD_SCENE, "BVH deeper than the reference's 64-entry traversal stack");
 
@@ -718,6 +727,7 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
   hipLaunchKernelGGL(lt_retile_kernel, dim3((n_prims + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->d_prims,
                      (float4*)ctx->d_tris, n_prims);
   LT_HIP_CHECK(ctx, hipGetLastError());
+  lap("free, malloc, upload scene");
   // The backend's own hierarchy over the same leaves (lt_retree.hpp says why the pixels cannot change), for every finite ray of
   // the non-counting kernels.  LT_RETREE=0 keeps the caller's splits (same structures, same walks).  A scene whose boxes do not
   // nest gets none: its rays walk the caller's tree one by one, in the reference's order.
@@ -729,7 +739,22 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
     const auto t0 = std::chrono::steady_clock::now();
     const char* sl = getenv("LT_RETREE_SLACK");
     // (height <= 30: the packet walks' stack, one VGPR, holds 2 * height + 2 entries at most; LT_RETREE=0: the caller's splits)
+    // (the leaf order table depends on the caller's tree alone: it is made by a thread of its own beside the build -- or, if that
+    // thread cannot be had, after it)
+    std::vector<uint32_t> rank8;
+    std::thread rankThread;
+    bool rankStarted = false;
+    std::atomic<bool> rankFailed{false};
+    try {
+      rankThread = std::thread([&]() {
+        try { lt_retree::reference_order(nodes, n_nodes, n_prims, rank8); } catch (...) { rankFailed = true; }   // (nothing escapes a thread)
+      });
+      rankStarted = true;
+    } catch (...) {
+    }
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{rankThread};   // (every exit below waits for it)
     const int h2 = (re && atoi(re) == 0) ? lt_retree::copy(nodes, n_nodes, 30, own) : lt_retree::build(nodes, n_nodes, 30, sl ? atoi(sl) : 2, own);
+    lap("own hierarchy (host build)");
     if (h2 >= 0) {
       ctx->retree_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
       const uint32_t n2 = (uint32_t)own.size();
@@ -740,9 +765,11 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
                          (const float*)ctx->d_prims, (float4*)ctx->d_pairs2, n2);
       LT_HIP_CHECK(ctx, hipGetLastError());
       // ... and the per-lane walks' 4-wide groups and leaf records, made from the same upload of the tree
+      lap("upload own tree, pair kernel");
       std::vector<uint32_t> children, groupOf;
       const int hw = lt_retree::collapse_wide(own, n_prims, children, groupOf);
       const uint32_t groups = (uint32_t)(children.size() / 4);
+      lap("collapse into 4-wide groups");
       // (the walk's stack: at most three waiting entries per level of groups and the four of the last one)
       bool ownOk = hw >= 0 && 3 * hw + 4 <= kOwnRows + kOwnDeep && (uint64_t)groups + n_prims + 1 < 0x7fffffffull;
       if (ownOk) {
@@ -771,6 +798,7 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
         (void)hipFree(d_children);
         (void)hipFree(d_groupOf);
         ownOk = bad == 0;   // (a bound off the grid cannot happen for a grid sized from the root's box)
+        lap("wide records (upload, kernels)");
       }
       if (!ownOk) {   // the scene then walks the caller's tree
         for (void** p : {&ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_wide}) { if (*p) (void)hipFree(*p); *p = nullptr; }
@@ -779,10 +807,11 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
         ctx->height2 = h2;
         ctx->n_wide = groups;
         ctx->wide_height = hw;
-        std::vector<uint32_t> rank8;
-        lt_retree::reference_order(nodes, n_nodes, n_prims, rank8);
+        if (rankThread.joinable()) rankThread.join();
+        if (!rankStarted || rankFailed) lt_retree::reference_order(nodes, n_nodes, n_prims, rank8);
         LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_rank8, rank8.size() * sizeof(uint32_t)));
         LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_rank8, rank8.data(), rank8.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        lap("leaf order table (host, upload)");
       }
       ctx->retree_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

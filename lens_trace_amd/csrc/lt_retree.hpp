@@ -318,7 +318,33 @@ inline void thread(std::vector<Node>& nodes) {
 //                       parent's group)
 // Returns the height of the group tree (groups above the deepest group), or -1 when two leaves refer to the same primitive
 // (the leaf records of the walk are indexed by primitive offset).
-inline int collapse_wide(const std::vector<Node>& own, uint32_t n_prims, std::vector<uint32_t>& children, std::vector<uint32_t>& groupOf) {
+// (the up to four nodes of the group that stands for interior node b; returns how many)
+inline int wide_kids(const std::vector<Node>& own, uint32_t b, uint32_t kids[4]) {
+  auto half_area = [&](uint32_t i) {
+    const Node& p = own[i];
+    const float dx = p.hi[0] - p.lo[0], dy = p.hi[1] - p.lo[1], dz = p.hi[2] - p.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  kids[0] = b + 1u; kids[1] = (uint32_t)own[b].off; kids[2] = kids[3] = 0xffffffffu;
+  int count = 2;
+  while (count < 4) {
+    int best = -1;
+    float bestArea = -1.0f;
+    for (int k = 0; k < count; k++)
+      if (own[kids[k]].cnt == 0) {
+        const float a = half_area(kids[k]);
+        if (a > bestArea) { bestArea = a; best = k; }   // (the first of equals: deterministic)
+      }
+    if (best < 0) break;
+    const uint32_t d = kids[best];
+    kids[best] = d + 1u;
+    kids[count++] = (uint32_t)own[d].off;
+  }
+  std::stable_partition(kids, kids + count, [&](uint32_t k) { return own[k].cnt == 0; });   // interior children first, leaves last
+  return count;
+}
+
+inline int collapse_wide(const std::vector<Node>& own, uint32_t n_prims, std::vector<uint32_t>& children, std::vector<uint32_t>& groupOf, int threads = 0) {
   const uint32_t n = (uint32_t)own.size();
   children.clear();
   groupOf.assign(n, 0xffffffffu);
@@ -330,40 +356,85 @@ inline int collapse_wide(const std::vector<Node>& own, uint32_t n_prims, std::ve
         seen[(uint32_t)nd.off] = true;
       }
   }
-  auto half_area = [&](uint32_t i) {
-    const Node& p = own[i];
-    const float dx = p.hi[0] - p.lo[0], dy = p.hi[1] - p.lo[1], dz = p.hi[2] - p.lo[2];
-    return dx * dy + dy * dz + dz * dx;
-  };
-  struct Item { uint32_t node; int depth; };
-  std::vector<Item> stack{{0u, 0}};
-  int height = 0;
-  while (!stack.empty()) {
-    const Item it = stack.back();
-    stack.pop_back();
-    height = std::max(height, it.depth);
-    uint32_t kids[4] = {it.node + 1u, (uint32_t)own[it.node].off, 0xffffffffu, 0xffffffffu};
-    int count = 2;
-    while (count < 4) {
-      int best = -1;
-      float bestArea = -1.0f;
-      for (int k = 0; k < count; k++)
-        if (own[kids[k]].cnt == 0) {
-          const float a = half_area(kids[k]);
-          if (a > bestArea) { bestArea = a; best = k; }   // (the first of equals: deterministic)
-        }
-      if (best < 0) break;
-      const uint32_t b = kids[best];
-      kids[best] = b + 1u;
-      kids[count++] = (uint32_t)own[b].off;
-    }
-    // interior children first (in slot order), leaves last
-    std::stable_partition(kids, kids + count, [&](uint32_t k) { return own[k].cnt == 0; });
-    groupOf[it.node] = (uint32_t)(children.size() / 4);
-    for (int k = 0; k < 4; k++) children.push_back(kids[k]);
-    for (int k = count - 1; k >= 0; k--)   // depth-first numbering: the first interior child is numbered next
-      if (own[kids[k]].cnt == 0) stack.push_back({kids[k], it.depth + 1});
+  if (threads <= 0) {
+    const char* e = getenv("LT_RETREE_THREADS");
+    threads = e ? std::max(1, std::min(64, atoi(e))) : std::min(16, available_cpus());
   }
+  if (n < 100000u) threads = 1;
+  // 1. which interior nodes get a group of their own (the others are dissolved into their parent's), top down: a queue of
+  //    subtrees [node, end) -- in pre-order a subtree is a range of indices -- large ones handed on, small ones walked to the
+  //    bottom by whoever takes them.  groupOf[b] = 0 marks a group's node for now.
+  struct Task { uint32_t node, end; int depth; };
+  std::mutex mx;
+  std::condition_variable cv;
+  std::vector<Task> queue{Task{0u, n, 0}};
+  int busy = 0, height = 0;
+  const uint32_t grain = std::max(4096u, n / (8u * (uint32_t)threads));
+  auto worker = [&]() {
+    std::unique_lock<std::mutex> lk(mx);
+    for (;;) {
+      cv.wait(lk, [&]() { return !queue.empty() || busy == 0; });
+      if (queue.empty()) return;
+      const Task first = queue.back();
+      queue.pop_back();
+      busy++;
+      lk.unlock();
+      std::vector<Task> local{first}, handOn;
+      int h = 0;
+      while (!local.empty()) {
+        const Task t = local.back();
+        local.pop_back();
+        h = std::max(h, t.depth);
+        groupOf[t.node] = 0u;
+        uint32_t kids[4];
+        const int count = wide_kids(own, t.node, kids);
+        for (int k = 0; k < count; k++) {
+          if (own[kids[k]].cnt != 0) continue;
+          // the child's subtree ends where the next node of the group (in index order) starts, or where the group's does
+          uint32_t end = t.end;
+          for (int j = 0; j < count; j++)
+            if (kids[j] > kids[k] && kids[j] < end) end = kids[j];
+          const Task c{kids[k], end, t.depth + 1};
+          if (threads > 1 && c.end - c.node > grain && t.end - t.node > 2u * grain) handOn.push_back(c); else local.push_back(c);
+        }
+      }
+      lk.lock();
+      height = std::max(height, h);
+      for (const Task& t : handOn) queue.push_back(t);
+      busy--;
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> pool;
+  try {
+    for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+  } catch (...) {
+  }
+  worker();
+  for (std::thread& th : pool) th.join();
+  pool.clear();
+  // 2. groups numbered in the order of their nodes (pre-order: a group's first interior child follows it closely)
+  uint32_t groups = 0;
+  for (uint32_t b = 0; b < n; b++)
+    if (groupOf[b] == 0u) groupOf[b] = groups++;
+  // 3. the groups' slots
+  children.assign(4 * (size_t)groups, 0xffffffffu);
+  auto fill = [&](uint32_t lo, uint32_t hi) {
+    for (uint32_t b = lo; b < hi; b++) {
+      if (groupOf[b] == 0xffffffffu) continue;
+      uint32_t kids[4];
+      const int count = wide_kids(own, b, kids);
+      for (int k = 0; k < count; k++) children[4 * (size_t)groupOf[b] + k] = kids[k];
+    }
+  };
+  try {
+    for (int t = 1; t < threads; t++) pool.emplace_back(fill, (uint32_t)((uint64_t)n * t / threads), (uint32_t)((uint64_t)n * (t + 1) / threads));
+  } catch (...) {
+  }
+  fill(0u, (uint32_t)((uint64_t)n / threads));
+  const size_t started = pool.size();
+  for (std::thread& th : pool) th.join();
+  for (int t = 1 + (int)started; t < threads; t++) fill((uint32_t)((uint64_t)n * t / threads), (uint32_t)((uint64_t)n * (t + 1) / threads));
   return height;
 }
 
