@@ -36,10 +36,11 @@ struct BackendPropertiesHIP {
   // with the device library's approximate leaf functions in correctly rounded forms (what the CPU oracle computes).
   uint32_t portableMath;
   uint32_t strictMath;
-  // Scene-change contract.  0 (default): every render() hashes the four scene buffers in full and re-uploads when anything
-  // changed -- the reference's "upload on every call" semantics (renderer_opencl.cpp:107-120) at the price of one pass over
-  // host memory (~20 ms for the 1 M-triangle scene).  != 0: the caller versions its scene -- the buffers are re-examined only
-  // when the pointers, sizes or this number differ from the previous call's.
+  // Scene-change contract.  0 (default): every render() hands the four scene buffers over with the frame, as the reference's
+  // callers do (renderer_opencl.cpp:107-120): they are hashed in full WHILE the frame renders (lt_hip_render_scene) and uploaded
+  // -- and the frame rendered again -- only when a byte changed; bench.py reports what that costs end to end
+  // (config.e2e_frame_ms_plugin, scene_hash_ms).  != 0: the caller versions its scene -- the buffers are looked at only when the
+  // pointers, sizes or this number differ from the previous call's.
   uint64_t sceneVersion;
 };
 

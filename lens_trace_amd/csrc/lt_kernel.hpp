@@ -56,7 +56,9 @@ __device__ __forceinline__ void render_square(const SceneDev& sc, const FramePar
 #endif
     }
   }
-  if (queueing && !queued) ((uint4*)sc.shadowQueue)[2 * (size_t)sc.shadowCap + qslot].x = kDeadSlot;   // (every slot of the square says what it holds)
+  // (every slot of the square says what it holds -- all 16 bytes of it: a wave's dwords 16 bytes apart would be sixteen
+  // partly written lines instead of four whole ones)
+  if (queueing && !queued) ((uint4*)sc.shadowQueue)[2 * (size_t)sc.shadowCap + qslot] = make_uint4(kDeadSlot, 0u, 0u, 0u);
 }
 
 // Registers: the traversal wants every wave slot (8 per SIMD = 64 VGPRs); the single-bounce programs fit that with a few
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(kBlock, LT_GI_STAGE_WAVES) void lt_gi_primary_kerne
     uint32_t slot;
     if (gp.directQueue) {
       slot = ((start + t) * fp.fusedFrames + frame) * (uint32_t)kBlock + threadIdx.x;
-      if (!alive) gp.q[0].m[slot].x = kDeadPath;
+      if (!alive) gp.q[0].m[slot] = make_uint4(kDeadPath, 0u, 0u, 0u);
     } else {
       slot = wave_append(&gp.counts[0], alive);
     }

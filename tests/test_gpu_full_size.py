@@ -155,8 +155,9 @@ def test_tile_mode_clamped_equals_linear_mode(renderer, wall):
 def test_whole_4k_frame_matches_reference_accumulator_kernel(renderer, wall, monkeypatch, yaw, build):
     """examples/accumulator/resources/kernels/accumulator.cl:113-217 (one work-item per pixel, private 64-entry stack) on the
     1 002 530-triangle buffers at 3840x2160, built with the reference's own (NULL) build options, against the HIP path's default
-    flavour -- the kernel bench.py times: packet walks over pair records, octant switches, the 20-row LDS stack, slow-path
-    squares first, both shadow-ray walks.  Bit for bit.  (And the strict flavour against the strict build of the same file.)"""
+    flavour -- the kernel bench.py times: the backend's own hierarchy, hand-written packet walks over its pair records (stack in
+    one register), octant switches, slow-path squares first, and the shadow rays through each of their walks -- as packets, per
+    lane over the 4-wide groups, queued for lt_trace_kernel.  Bit for bit.  (And the strict flavour against the strict build of the same file.)"""
     from lens_trace_amd.renderer import RenderPropertiesHIP as DefaultFlavourProps
     from oracle import ref_gpu
     if not ref_gpu.available("accumulator", build):
