@@ -74,3 +74,20 @@ def test_plain_invocation_with_gpus_2_starts_its_own_ranks():
     assert len(lines) == 1, out
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "tiles interleaved over 2 GPUs" in d["config"]["workload"]
+
+
+def test_full_workload_line_prices_the_built_kernel_or_says_why_not():
+    """The headline workload itself (a few steps, no side figures): `roofline.frac` is a fraction of a stated issue peak taken from the
+    counter summary under profiles/ whose `build` is THIS build of the kernels (bench.build_identity), with the measured HBM side
+    beside it -- or it is null and `roofline.note` says that the committed counters belong to another build.  Never a number
+    computed from stale counters."""
+    d = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-soup", "--no-e2e"])
+    r = d["roofline"]
+    assert d["config"]["triangles"] == 1002530 and d["config"]["width"] == 3840 and d["value"] > 5000
+    if r["frac"] is None:
+        assert "stale" in r.get("note", ""), r
+    else:
+        assert r["bound"] in ("valu-issue", "scalar-issue") and 0.0 < r["frac"] <= 1.0
+        assert 0.0 < r["hbm_measured_frac"] <= 1.0 and r["traffic"] > 0 and r["source"].startswith("profiles/r")
+        # SURVEY 8(d)'s bytes of the reference algorithm per launch exceed what the chip can move: the kernel does not move them
+        assert r["algorithmic_gbs"] > r["hbm_peak_gbs"] and r["on_chip_reuse_factor"] > 1.0
