@@ -20,7 +20,7 @@ instruction-issue pipe, from the rocprofv3 PMC passes of this same command (tool
 profiles/<round>/issue_profile.json): `achieved` = that pipe's instructions per launch (a property of the workload and the
 build) / its units / (the launch time measured LIVE here with HIP events x the profiled shader clock), `peak` = the pipe's issue
 rate (MI355X_MICROARCH.md: wave64 VALU 0.5 instructions per SIMD-cycle; one scalar instruction per CU-cycle), `frac` <= 1.
-Beside it: `traffic` = measured HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), `hbm_measured_gbs` / `hbm_measured_frac`
+Beside it: `traffic` = measured HBM bytes per launch (FETCH_SIZE + WRITE_SIZE; FETCH_SIZE doubled for streaming kernels only: profiles/r3/gather_calibration_fetch_size.txt), `hbm_measured_gbs` / `hbm_measured_frac`
 against the 8 TB/s peak, and `algorithmic_gbs` = SURVEY section 8(d)'s bytes (32 B x node visits + 76 B x triangle tests +
 36 B x pixel-samples, the REFERENCE algorithm's counts, measured once with device atomics and equal to the CPU oracle's) per
 launch / launch time -- several times the HBM peak, which is what "on_chip_reuse_factor" states.
