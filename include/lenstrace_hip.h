@@ -246,6 +246,15 @@ int lt_hip_own_hierarchy(const void* nodes, uint64_t node_bytes, int height_slac
 int lt_hip_own_wide(const void* own_nodes, uint64_t node_bytes, uint32_t n_prims, float* origin_step, void* out_slots, uint64_t out_bytes,
                     uint32_t* out_groups);
 
+/* Diagnostics: copies one of the structures lt_hip_set_scene derived for the resident scene back to the host (tests hold the
+ * device-side preparation, lens_trace_amd/csrc/lt_prep.hip, against the host-side one, lt_retree.hpp, with it).
+ * what: 0 = the own tree (32-byte nodes, pre-order), 1 = the leaf order table (8 x uint32 per primitive), 2 = the per-lane
+ * walks' array (64-byte grid header, then 64-byte records: groups, leaf records by primitive offset, the sentinel),
+ * 3 = four uint32: own-tree height, group-tree height, groups, 1 if the device prepared the scene (0: the host).
+ * out == NULL: only *out_bytes (the size) is set.  LT_ERR_NO_SCENE without a scene; *out_bytes = 0 when the scene has no such
+ * structure (it then walks the caller's tree). */
+int lt_hip_read_scene_structure(lt_hip_context* ctx, int what, void* out, uint64_t capacity, uint64_t* out_bytes);
+
 /* Statistics of the most recent render call on ctx (waits for it to finish). */
 int lt_hip_get_stats(lt_hip_context* ctx, lt_hip_stats* out);
 

@@ -25,7 +25,7 @@ RENDER_FLAG_NO_WALK_TIMING = 32
 EXPORTS = ["lt_hip_abi_version", "lt_hip_create", "lt_hip_destroy", "lt_hip_last_error", "lt_hip_program_from_path",
            "lt_hip_resolve_program",
            "lt_hip_set_scene", "lt_hip_output_floats", "lt_hip_render", "lt_hip_render_scene", "lt_hip_render_device", "lt_hip_untile",
-           "lt_hip_synchronize", "lt_hip_get_stats", "lt_hip_own_hierarchy", "lt_hip_own_wide"]
+           "lt_hip_synchronize", "lt_hip_get_stats", "lt_hip_own_hierarchy", "lt_hip_own_wide", "lt_hip_read_scene_structure"]
 
 
 class RenderDesc(ctypes.Structure):

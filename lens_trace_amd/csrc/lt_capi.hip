@@ -3,6 +3,7 @@
 #include "lt_kernel.hpp"
 #include "lt_retree.hpp"
 #include "lt_own16.hpp"
+#include "lt_prep.hpp"
 
 #include "../../include/lenstrace_hip.h"
 
@@ -192,6 +193,7 @@ struct lt_hip_context {
   uint32_t n_nodes = 0, n_prims = 0, n_mats = 0;
   int bvh_height = 0;
   bool has_scene = false;
+  bool device_prepared = false;      // the resident scene's derived structures were made by lt_prep.hip (not by lt_retree.hpp on the host)
   SceneHash scene_hash{};                                    // content hashes (one per buffer) ...
   uint64_t scene_sizes[4] = {0, 0, 0, 0};                   // ... and sizes of the resident scene (lt_hip_set_scene)
   uint32_t scene_uploads = 0, scene_reused = 0;
@@ -305,6 +307,7 @@ static void free_scene(lt_hip_context* ctx) {
     *p = nullptr;
   }
   ctx->has_scene = false;
+  ctx->device_prepared = false;
 }
 
 extern "C" int lt_hip_destroy(lt_hip_context* ctx) {
@@ -632,6 +635,120 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
   }
 }
 
+// The device path of lt_hip_set_scene.  kDeviceDeclined: nothing of ctx was touched, the host path decides.
+constexpr int kDeviceDeclined = -1000;
+static int set_scene_on_device(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims, uint64_t prim_bytes,
+                               const void* materials, uint64_t material_bytes, const void* lights, uint64_t light_bytes, const SceneHash& hash,
+                               bool timing) {
+  const uint32_t n_nodes = (uint32_t)(node_bytes / 32), n_prims = (uint32_t)(prim_bytes / 76), n_mats = (uint32_t)(material_bytes / 32);
+  auto tmark = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[lt set_scene] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tmark).count());
+    tmark = now;
+  };
+  {   // the light list is 260 bytes: checked here
+    uint32_t lc;
+    memcpy(&lc, lights, 4);
+    if (lc > 64) return kDeviceDeclined;
+    for (uint32_t i = 0; i < lc; i++) {
+      uint32_t pi;
+      memcpy(&pi, (const uint8_t*)lights + 4 + 4 * i, 4);
+      if (pi >= n_prims) return kDeviceDeclined;
+    }
+  }
+  LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  void *d_nodes = nullptr, *d_prims = nullptr;
+  struct Guard {   // (whatever is still set when this returns is freed)
+    void** a; void** b; lt_prep::Out* o;
+    ~Guard() { if (*a) (void)hipFree(*a); if (*b) (void)hipFree(*b); if (o) lt_prep::release(*o); }
+  };
+  lt_prep::Out prep;
+  Guard guard{&d_nodes, &d_prims, &prep};
+  LT_HIP_CHECK(ctx, hipMalloc(&d_nodes, node_bytes));
+  LT_HIP_CHECK(ctx, hipMalloc(&d_prims, prim_bytes));
+  LT_HIP_CHECK(ctx, hipMemcpyAsync(d_nodes, nodes, node_bytes, hipMemcpyHostToDevice, ctx->stream));
+  LT_HIP_CHECK(ctx, hipMemcpyAsync(d_prims, prims, prim_bytes, hipMemcpyHostToDevice, ctx->stream));
+  lap("upload nodes, primitives");
+  const char* re = getenv("LT_RETREE");
+  const char* sl = getenv("LT_RETREE_SLACK");
+  const auto t0 = std::chrono::steady_clock::now();
+  // (height <= 30: the packet walks' stack, one VGPR, holds 2 * height + 2 entries at most; LT_RETREE=0: the caller's splits)
+  LT_HIP_CHECK(ctx, lt_prep::run(d_nodes, n_nodes, d_prims, n_prims, n_mats, 30, sl ? atoi(sl) : 2, !(re && atoi(re) == 0), ctx->stream, prep));
+  if (timing) fprintf(stderr, "[lt set_scene] device: checks + leaf order %.2f ms, own hierarchy %.2f ms (%d levels), 4-wide groups %.2f ms, flags %u\n",
+                      prep.ms_check, prep.ms_build, prep.levels, prep.ms_wide, prep.flags);
+  if (prep.flags != 0 || prep.bvh_height > kMaxStack) return kDeviceDeclined;
+  lap("device preparation");
+  // from here on the scene is good: it replaces the resident one
+  LT_HIP_CHECK(ctx, hipDeviceSynchronize());
+  free_scene(ctx);
+  ctx->d_nodes = d_nodes; d_nodes = nullptr;
+  ctx->d_prims = d_prims; d_prims = nullptr;
+  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_tris, (size_t)n_prims * 48));
+  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_mats, material_bytes));
+  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_lights, light_bytes));
+  LT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_mats, materials, material_bytes, hipMemcpyHostToDevice, ctx->stream));
+  LT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_lights, lights, light_bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(lt_retile_kernel, dim3((n_prims + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->d_prims, (float4*)ctx->d_tris, n_prims);
+  LT_HIP_CHECK(ctx, hipGetLastError());
+  ctx->height2 = 0;
+  ctx->retree_ms = 0.0f;
+  const uint32_t n2 = prep.n_own, groups = prep.groups;
+  const int hw = prep.wide_height;
+  bool ownOk = hw >= 0 && groups > 0 && 3 * hw + 4 <= kOwnRows + kOwnDeep && (uint64_t)groups + n_prims + 1 < 0x7fffffffull;
+  if (ownOk) {
+    ctx->d_nodes2 = prep.d_nodes2; prep.d_nodes2 = nullptr;
+    ctx->d_rank8 = prep.d_rank8; prep.d_rank8 = nullptr;
+    LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pairs2, (size_t)n2 * 64));
+    hipLaunchKernelGGL(lt_own_pair_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2, (const float*)ctx->d_prims,
+                       (float4*)ctx->d_pairs2, n2);
+    LT_HIP_CHECK(ctx, hipGetLastError());
+    Own16Frame fr;
+    for (int a = 0; a < 3; a++) lt_own16::frame(prep.root_lo[a], prep.root_hi[a], fr.O[a], fr.S[a]);
+    const size_t records = (size_t)groups + n_prims + 1;
+    LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_wide, records * 64 + 64));
+    const float head[16] = {0, 0, 0, 0, 0, 0, 0, 0, fr.O[0], fr.O[1], fr.O[2], 0.0f, fr.S[0], fr.S[1], fr.S[2], 0.0f};
+    LT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_wide, head, sizeof(head), hipMemcpyHostToDevice, ctx->stream));
+    LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long), ctx->stream));
+    uint4* wide = (uint4*)ctx->d_wide + 4;
+    hipLaunchKernelGGL(lt_wide_kernel, dim3((4 * groups + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2,
+                       (const uint32_t*)prep.d_children, (const uint32_t*)prep.d_groupOf, wide, groups, n_prims, fr, (uint32_t*)ctx->d_stats);
+    LT_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(lt_wide_leaf_kernel, dim3((n2 + 1 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2,
+                       (const float*)ctx->d_prims, (float4*)wide, n2, groups, n_prims);
+    LT_HIP_CHECK(ctx, hipGetLastError());
+    uint32_t bad = 0;
+    LT_HIP_CHECK(ctx, hipMemcpyAsync(&bad, ctx->d_stats, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+    LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ownOk = bad == 0;
+  }
+  if (!ownOk) {   // the scene then walks the caller's tree
+    for (void** p : {&ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_wide, &ctx->d_rank8}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+  } else {
+    ctx->n_nodes2 = n2;
+    ctx->height2 = prep.own_height;
+    ctx->n_wide = groups;
+    ctx->wide_height = hw;
+  }
+  lt_prep::release(prep);
+  LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->retree_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  lap("pair and wide records");
+  ctx->n_nodes = n_nodes;
+  ctx->n_prims = n_prims;
+  ctx->n_mats = n_mats;
+  ctx->bvh_height = prep.bvh_height;
+  ctx->has_scene = true;
+  ctx->scene_hash = hash;
+  ctx->scene_sizes[0] = node_bytes; ctx->scene_sizes[1] = prim_bytes; ctx->scene_sizes[2] = material_bytes; ctx->scene_sizes[3] = light_bytes;
+  ctx->scene_uploads++;
+  ctx->device_prepared = true;
+  for (int& m : ctx->shadow_mode) m = -1;
+  ctx->shadow_modes.clear();
+  return LT_OK;
+}
+
 static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims, uint64_t prim_bytes, const void* materials,
                           uint64_t material_bytes, const void* lights, uint64_t light_bytes, const SceneHash* known_hash) {
   if (!ctx) return LT_ERR_INVALID_ARGUMENT;
@@ -707,6 +824,19 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
     tmark = now;
   };
   std::string msg;
+  // Scene preparation on the device (lt_prep.hip): nodes and primitives go up first, kernels check them, make the leaf order
+  // table, build the own hierarchy and collapse it; the host passes below are what remains for scenes that path declines
+  // (a malformed buffer -- the host words the error --, a tree that is not in the scene builder's pre-order, boxes that do not
+  // nest) and for small ones, where a host build costs less than the launches.  LT_DEVICE_BUILD=0 / 1: never / whenever possible.
+  {
+    const char* db = getenv("LT_DEVICE_BUILD");
+    const bool device = db ? atoi(db) != 0 : n_nodes >= 8192u;
+    if (device) {
+      const int rc = set_scene_on_device(ctx, nodes, node_bytes, prims, prim_bytes, materials, material_bytes, lights, light_bytes, hash, timing);
+      if (rc != kDeviceDeclined) return rc;
+      lap("device preparation declined");
+    }
+  }
   const int height = validate_scene((const uint8_t*)nodes, n_nodes, (const uint8_t*)prims, n_prims, n_mats, (const uint8_t*)lights, msg);
   lap("validate");
   if (height < 0) return fail(ctx, LT_ERR_BAD_SCENE, msg);
@@ -1713,6 +1843,28 @@ extern "C" int lt_hip_synchronize(lt_hip_context* ctx, void* hip_stream) {
   if (!ctx) return LT_ERR_INVALID_ARGUMENT;
   LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   LT_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)hip_stream));
+  return LT_OK;
+}
+
+extern "C" int lt_hip_read_scene_structure(lt_hip_context* ctx, int what, void* out, uint64_t capacity, uint64_t* out_bytes) {
+  if (!ctx) return LT_ERR_INVALID_ARGUMENT;
+  if (!out_bytes || what < 0 || what > 3) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "lt_hip_read_scene_structure: bad arguments");
+  if (!ctx->has_scene) return fail(ctx, LT_ERR_NO_SCENE, "no scene uploaded");
+  LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const bool own = ctx->d_nodes2 && ctx->d_wide && ctx->d_rank8;
+  uint32_t info[4] = {(uint32_t)ctx->height2, (uint32_t)ctx->wide_height, ctx->n_wide, ctx->device_prepared ? 1u : 0u};
+  const void* src = nullptr;
+  uint64_t bytes = 0;
+  if (what == 3) { bytes = sizeof(info); }
+  else if (own && what == 0) { src = ctx->d_nodes2; bytes = (uint64_t)ctx->n_nodes2 * 32; }
+  else if (own && what == 1) { src = ctx->d_rank8; bytes = (uint64_t)ctx->n_prims * 32; }
+  else if (own && what == 2) { src = ctx->d_wide; bytes = ((uint64_t)ctx->n_wide + ctx->n_prims + 1) * 64 + 64; }
+  *out_bytes = bytes;
+  if (!out || bytes == 0) return LT_OK;
+  if (capacity < bytes) return fail(ctx, LT_ERR_INVALID_ARGUMENT, "lt_hip_read_scene_structure: buffer too small");
+  if (what == 3) { memcpy(out, info, sizeof(info)); return LT_OK; }
+  LT_HIP_CHECK(ctx, hipDeviceSynchronize());
+  LT_HIP_CHECK(ctx, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
   return LT_OK;
 }
 

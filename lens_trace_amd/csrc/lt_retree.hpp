@@ -36,7 +36,26 @@
 #include <thread>
 #include <vector>
 
+#if defined(__HIPCC__) || defined(__HIP__)
+#define LT_RETREE_HD __host__ __device__
+#else
+#define LT_RETREE_HD
+#endif
+
 namespace lt_retree {
+
+// Floats as unsigned integers in the same order (-0 below +0; NaN does not occur: the boxes are checked first).  Box unions are
+// taken in this order on the host and on the device (lt_prep.hip: atomic min / max on these integers), so that the two builds
+// agree on the sign of a zero bound too.
+LT_RETREE_HD inline uint32_t ordered(float f) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, f);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+LT_RETREE_HD inline float unordered(uint32_t o) {
+  return __builtin_bit_cast(float, o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu));
+}
+LT_RETREE_HD inline float tmin(float a, float b) { return ordered(b) < ordered(a) ? b : a; }
+LT_RETREE_HD inline float tmax(float a, float b) { return ordered(b) > ordered(a) ? b : a; }
 
 struct Node {   // LinearBVHNode (include/lens_trace/acceleration_structure_explicit.h:20-32)
   float lo[3], hi[3];
@@ -118,10 +137,10 @@ inline int build_range(const Node* nd, const float* centroid, std::vector<uint32
       const Node& p = nd[order[i]];
       const float* c = centroid + 3 * (size_t)order[i];
       for (int a = 0; a < 3; a++) {
-        node.lo[a] = std::min(node.lo[a], p.lo[a]);
-        node.hi[a] = std::max(node.hi[a], p.hi[a]);
-        cmin[a] = std::min(cmin[a], c[a]);
-        cmax[a] = std::max(cmax[a], c[a]);
+        node.lo[a] = tmin(node.lo[a], p.lo[a]);
+        node.hi[a] = tmax(node.hi[a], p.hi[a]);
+        cmin[a] = tmin(cmin[a], c[a]);
+        cmax[a] = tmax(cmax[a], c[a]);
       }
     }
     const float d[3] = {cmax[0] - cmin[0], cmax[1] - cmin[1], cmax[2] - cmin[2]};
@@ -147,7 +166,7 @@ inline int build_range(const Node* nd, const float* centroid, std::vector<uint32
           if (!(d[a] > 0.0f)) continue;
           Bin& b = bins[a][std::min(kBins - 1, std::max(0, (int)((c[a] - cmin[a]) * scale[a])))];
           b.count++;
-          for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], p.lo[k]); b.hi[k] = std::max(b.hi[k], p.hi[k]); }
+          for (int k = 0; k < 3; k++) { b.lo[k] = tmin(b.lo[k], p.lo[k]); b.hi[k] = tmax(b.hi[k], p.hi[k]); }
         }
       }
       auto half_area = [](const float* lo, const float* hi) {
@@ -165,7 +184,7 @@ inline int build_range(const Node* nd, const float* centroid, std::vector<uint32
         uint32_t c = 0;
         for (int b = kBins - 1; b >= 0; b--) {
           const Bin& bn = bins[a][b];
-          if (bn.count) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], bn.lo[k]); hi[k] = std::max(hi[k], bn.hi[k]); }
+          if (bn.count) for (int k = 0; k < 3; k++) { lo[k] = tmin(lo[k], bn.lo[k]); hi[k] = tmax(hi[k], bn.hi[k]); }
           c += bn.count;
           rightCount[b] = c;
           rightArea[b] = c ? half_area(lo, hi) : 0.0f;
@@ -174,7 +193,7 @@ inline int build_range(const Node* nd, const float* centroid, std::vector<uint32
         c = 0;
         for (int b = 0; b + 1 < kBins; b++) {   // split after bin b
           const Bin& bn = bins[a][b];
-          if (bn.count) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], bn.lo[k]); hi[k] = std::max(hi[k], bn.hi[k]); }
+          if (bn.count) for (int k = 0; k < 3; k++) { lo[k] = tmin(lo[k], bn.lo[k]); hi[k] = tmax(hi[k], bn.hi[k]); }
           c += bn.count;
           const uint32_t rc = rightCount[b + 1];
           if (c == 0 || rc == 0 || c > maxChild || rc > maxChild) continue;
@@ -192,11 +211,16 @@ inline int build_range(const Node* nd, const float* centroid, std::vector<uint32
         split = true;
       }
     }
-    if (!split && d[dim] > 0.0f) {   // median of the largest centroid extent (no plane separates the centroids, or no room under the height limit)
-      std::nth_element(order.begin() + r.start, order.begin() + mid, order.begin() + r.end, [&](uint32_t a, uint32_t b) {
-        const float ca = centroid[3 * (size_t)a + dim], cb = centroid[3 * (size_t)b + dim];
-        return ca < cb || (ca == cb && a < b);
-      });
+    if (!split && d[dim] > 0.0f) {
+      // median of the largest centroid extent (no plane separates the centroids under the height limit, or two leaves): the
+      // count / 2 leaves with the smallest (centroid, leaf index) go left, both halves in the order they stand in -- a function
+      // of the set alone and of that order, which the device build reproduces with a selection and a stable partition
+      auto key = [&](uint32_t i) { return ((uint64_t)ordered(centroid[3 * (size_t)i + dim]) << 32) | i; };
+      std::vector<uint64_t> keys(count);
+      for (uint32_t i = 0; i < count; i++) keys[i] = key(order[r.start + i]);
+      std::nth_element(keys.begin(), keys.begin() + count / 2, keys.end());
+      const uint64_t pivot = keys[count / 2];
+      std::stable_partition(order.begin() + r.start, order.begin() + r.end, [&](uint32_t i) { return key(i) < pivot; });
     }
     node.axis = (uint8_t)dim;
     node.cnt = 0;
@@ -308,7 +332,7 @@ inline int build(const void* nodes, uint32_t n_nodes, int maxHeight, int slack, 
 // Returns the height of the group tree (groups above the deepest group), or -1 when two leaves refer to the same primitive
 // (the leaf records of the walk are indexed by primitive offset).
 // (the up to four nodes of the group that stands for interior node b; returns how many)
-inline int wide_kids(const std::vector<Node>& own, uint32_t b, uint32_t kids[4]) {
+LT_RETREE_HD inline int wide_kids(const Node* own, uint32_t b, uint32_t kids[4]) {
   auto half_area = [&](uint32_t i) {
     const Node& p = own[i];
     const float dx = p.hi[0] - p.lo[0], dy = p.hi[1] - p.lo[1], dz = p.hi[2] - p.lo[2];
@@ -329,9 +353,15 @@ inline int wide_kids(const std::vector<Node>& own, uint32_t b, uint32_t kids[4])
     kids[best] = d + 1u;
     kids[count++] = (uint32_t)own[d].off;
   }
-  std::stable_partition(kids, kids + count, [&](uint32_t k) { return own[k].cnt == 0; });   // interior children first, leaves last
+  // interior children first, leaves last, each kind in the order it stands in (a stable partition of at most four)
+  uint32_t sorted[4];
+  int m = 0;
+  for (int k = 0; k < count; k++) if (own[kids[k]].cnt == 0) sorted[m++] = kids[k];
+  for (int k = 0; k < count; k++) if (own[kids[k]].cnt != 0) sorted[m++] = kids[k];
+  for (int k = 0; k < count; k++) kids[k] = sorted[k];
   return count;
 }
+inline int wide_kids(const std::vector<Node>& own, uint32_t b, uint32_t kids[4]) { return wide_kids(own.data(), b, kids); }
 
 inline int collapse_wide(const std::vector<Node>& own, uint32_t n_prims, std::vector<uint32_t>& children, std::vector<uint32_t>& groupOf, int threads = 0) {
   const uint32_t n = (uint32_t)own.size();

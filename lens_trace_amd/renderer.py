@@ -168,6 +168,24 @@ class RendererHIP:
     def synchronize(self, stream=0):
         self._check(self._L.lt_hip_synchronize(self._ctx, ctypes.c_void_p(stream)))
 
+    def scene_structure(self, what):
+        """lt_hip_read_scene_structure: 0 own tree (NODE_DTYPE array), 1 leaf order table (n_prims x 8 uint32), 2 the per-lane walks'
+        array (bytes), 3 (own height, group-tree height, groups, prepared on the device).  None when the scene has no such structure."""
+        from . import scene as sc
+        n = ctypes.c_uint64(0)
+        self._check(self._L.lt_hip_read_scene_structure(self._ctx, what, None, ctypes.c_uint64(0), ctypes.byref(n)))
+        if n.value == 0:
+            return None
+        buf = np.zeros(n.value, dtype=np.uint8)
+        self._check(self._L.lt_hip_read_scene_structure(self._ctx, what, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(buf.nbytes), ctypes.byref(n)))
+        if what == 0:
+            return buf.view(sc.NODE_DTYPE)
+        if what == 1:
+            return buf.view(np.uint32).reshape(-1, 8)
+        if what == 3:
+            return tuple(int(x) for x in buf.view(np.int32))
+        return buf
+
     def stats(self):
         s = C.Stats()
         self._check(self._L.lt_hip_get_stats(self._ctx, ctypes.byref(s)))
