@@ -176,8 +176,53 @@ struct SceneHash {
   bool operator==(const SceneHash& o) const { return memcmp(buf, o.buf, sizeof(buf)) == 0; }
 };
 
+// Device buffers of scenes gone by, kept for the next scene of the same shape: an animation hands over buffers of the same sizes
+// frame after frame, and a hipFree / hipMalloc pair per buffer (a dozen of them, each a device-wide wait) was a tenth of
+// lt_hip_set_scene.  Exact sizes only; at most kSpareCap bytes lie idle (LT_SCENE_POOL_BYTES, 0: every buffer goes straight
+// back to the runtime).
+struct ScenePool {
+  std::multimap<size_t, void*> spare;
+  std::map<void*, size_t> sizes;   // of every buffer this pool handed out
+  size_t spareBytes = 0, cap = (size_t)8 << 30;
+  hipError_t get(void** p, size_t bytes) {
+    if (bytes == 0) bytes = 4;
+    auto it = spare.find(bytes);
+    if (it != spare.end()) {
+      *p = it->second;
+      spareBytes -= bytes;
+      spare.erase(it);
+      return hipSuccess;
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && !spare.empty()) {   // (memory is short: the idle buffers go first)
+      clear();
+      e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) sizes[*p] = bytes;
+    return e;
+  }
+  void put(void* p) {
+    if (!p) return;
+    auto it = sizes.find(p);
+    if (it == sizes.end()) { (void)hipFree(p); return; }
+    const size_t bytes = it->second;
+    if (bytes > cap) { sizes.erase(it); (void)hipFree(p); return; }
+    if (spareBytes + bytes > cap) clear();
+    spare.emplace(bytes, p);
+    spareBytes += bytes;
+  }
+  void clear() {
+    for (auto& kv : spare) { sizes.erase(kv.second); (void)hipFree(kv.second); }
+    spare.clear();
+    spareBytes = 0;
+  }
+  static hipError_t get_cb(void* self, void** p, size_t bytes) { return ((ScenePool*)self)->get(p, bytes); }
+  static void put_cb(void* self, void* p) { ((ScenePool*)self)->put(p); }
+};
+
 struct lt_hip_context {
   int device = -1;
+  ScenePool pool;
   std::string err;
   hipStream_t stream = nullptr;      // own stream for lt_hip_render
   void *d_nodes = nullptr, *d_tris = nullptr, *d_prims = nullptr, *d_mats = nullptr, *d_lights = nullptr;
@@ -269,6 +314,7 @@ extern "C" int lt_hip_create(int device_index, lt_hip_context** out_ctx) {
   lt_hip_context* ctx = new lt_hip_context();
   ctx->device = device_index;
   ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("LT_SCENE_POOL_BYTES")) ctx->pool.cap = (size_t)strtoull(e, nullptr, 10);
   auto bail = [&](const char* what, hipError_t er) {
     std::string m = std::string(what) + ": " + hipGetErrorString(er);
     delete ctx;
@@ -303,7 +349,7 @@ extern "C" int lt_hip_create(int device_index, lt_hip_context** out_ctx) {
 
 static void free_scene(lt_hip_context* ctx) {
   for (void** p : {&ctx->d_nodes, &ctx->d_tris, &ctx->d_prims, &ctx->d_mats, &ctx->d_lights, &ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_rank8, &ctx->d_wide}) {
-    if (*p) (void)hipFree(*p);
+    if (*p) ctx->pool.put(*p);
     *p = nullptr;
   }
   ctx->has_scene = false;
@@ -315,6 +361,7 @@ extern "C" int lt_hip_destroy(lt_hip_context* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   free_scene(ctx);
+  ctx->pool.clear();
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);
   for (hipEvent_t e : ctx->out_ev) if (e) (void)hipEventDestroy(e);
@@ -629,7 +676,11 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
                                 uint64_t prim_bytes, const void* materials, uint64_t material_bytes, const void* lights,
                                 uint64_t light_bytes) {
   try {
-    return set_scene_impl(ctx, nodes, node_bytes, prims, prim_bytes, materials, material_bytes, lights, light_bytes, nullptr);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = set_scene_impl(ctx, nodes, node_bytes, prims, prim_bytes, materials, material_bytes, lights, light_bytes, nullptr);
+    if (getenv("LT_DEBUG_SCENE_TIMING"))
+      fprintf(stderr, "[lt set_scene] %-28s %7.2f ms\n", "lt_hip_set_scene, all of it", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return rc;
   } catch (const std::exception& e) {   // (std::bad_alloc, std::system_error of a thread: nothing may cross the C ABI)
     return fail(ctx, LT_ERR_HIP, std::string("lt_hip_set_scene: ") + e.what());
   }
@@ -660,14 +711,15 @@ static int set_scene_on_device(lt_hip_context* ctx, const void* nodes, uint64_t 
   }
   LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   void *d_nodes = nullptr, *d_prims = nullptr;
-  struct Guard {   // (whatever is still set when this returns is freed)
-    void** a; void** b; lt_prep::Out* o;
-    ~Guard() { if (*a) (void)hipFree(*a); if (*b) (void)hipFree(*b); if (o) lt_prep::release(*o); }
+  const lt_prep::Allocator al{&ctx->pool, &ScenePool::get_cb, &ScenePool::put_cb};
+  struct Guard {   // (whatever is still set when this returns goes back)
+    ScenePool& pool; const lt_prep::Allocator& al; void** a; void** b; lt_prep::Out* o;
+    ~Guard() { pool.put(*a); pool.put(*b); lt_prep::release(*o, al); }
   };
   lt_prep::Out prep;
-  Guard guard{&d_nodes, &d_prims, &prep};
-  LT_HIP_CHECK(ctx, hipMalloc(&d_nodes, node_bytes));
-  LT_HIP_CHECK(ctx, hipMalloc(&d_prims, prim_bytes));
+  Guard guard{ctx->pool, al, &d_nodes, &d_prims, &prep};
+  LT_HIP_CHECK(ctx, ctx->pool.get(&d_nodes, node_bytes));
+  LT_HIP_CHECK(ctx, ctx->pool.get(&d_prims, prim_bytes));
   LT_HIP_CHECK(ctx, hipMemcpyAsync(d_nodes, nodes, node_bytes, hipMemcpyHostToDevice, ctx->stream));
   LT_HIP_CHECK(ctx, hipMemcpyAsync(d_prims, prims, prim_bytes, hipMemcpyHostToDevice, ctx->stream));
   lap("upload nodes, primitives");
@@ -675,7 +727,7 @@ static int set_scene_on_device(lt_hip_context* ctx, const void* nodes, uint64_t 
   const char* sl = getenv("LT_RETREE_SLACK");
   const auto t0 = std::chrono::steady_clock::now();
   // (height <= 30: the packet walks' stack, one VGPR, holds 2 * height + 2 entries at most; LT_RETREE=0: the caller's splits)
-  LT_HIP_CHECK(ctx, lt_prep::run(d_nodes, n_nodes, d_prims, n_prims, n_mats, 30, sl ? atoi(sl) : 2, !(re && atoi(re) == 0), ctx->stream, prep));
+  LT_HIP_CHECK(ctx, lt_prep::run(d_nodes, n_nodes, d_prims, n_prims, n_mats, 30, sl ? atoi(sl) : 2, !(re && atoi(re) == 0), ctx->stream, al, prep));
   if (timing) fprintf(stderr, "[lt set_scene] device: checks + leaf order %.2f ms, own hierarchy %.2f ms (%d levels), 4-wide groups %.2f ms, flags %u\n",
                       prep.ms_check, prep.ms_build, prep.levels, prep.ms_wide, prep.flags);
   if (prep.flags != 0 || prep.bvh_height > kMaxStack) return kDeviceDeclined;
@@ -683,11 +735,12 @@ static int set_scene_on_device(lt_hip_context* ctx, const void* nodes, uint64_t 
   // from here on the scene is good: it replaces the resident one
   LT_HIP_CHECK(ctx, hipDeviceSynchronize());
   free_scene(ctx);
+  lap("free the resident scene");
   ctx->d_nodes = d_nodes; d_nodes = nullptr;
   ctx->d_prims = d_prims; d_prims = nullptr;
-  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_tris, (size_t)n_prims * 48));
-  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_mats, material_bytes));
-  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_lights, light_bytes));
+  LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_tris, (size_t)n_prims * 48));
+  LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_mats, material_bytes));
+  LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_lights, light_bytes));
   LT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_mats, materials, material_bytes, hipMemcpyHostToDevice, ctx->stream));
   LT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_lights, lights, light_bytes, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(lt_retile_kernel, dim3((n_prims + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->d_prims, (float4*)ctx->d_tris, n_prims);
@@ -700,14 +753,14 @@ static int set_scene_on_device(lt_hip_context* ctx, const void* nodes, uint64_t 
   if (ownOk) {
     ctx->d_nodes2 = prep.d_nodes2; prep.d_nodes2 = nullptr;
     ctx->d_rank8 = prep.d_rank8; prep.d_rank8 = nullptr;
-    LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pairs2, (size_t)n2 * 64));
+    LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_pairs2, (size_t)n2 * 64));
     hipLaunchKernelGGL(lt_own_pair_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2, (const float*)ctx->d_prims,
                        (float4*)ctx->d_pairs2, n2);
     LT_HIP_CHECK(ctx, hipGetLastError());
     Own16Frame fr;
     for (int a = 0; a < 3; a++) lt_own16::frame(prep.root_lo[a], prep.root_hi[a], fr.O[a], fr.S[a]);
     const size_t records = (size_t)groups + n_prims + 1;
-    LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_wide, records * 64 + 64));
+    LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_wide, records * 64 + 64));
     const float head[16] = {0, 0, 0, 0, 0, 0, 0, 0, fr.O[0], fr.O[1], fr.O[2], 0.0f, fr.S[0], fr.S[1], fr.S[2], 0.0f};
     LT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_wide, head, sizeof(head), hipMemcpyHostToDevice, ctx->stream));
     LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long), ctx->stream));
@@ -720,21 +773,23 @@ static int set_scene_on_device(lt_hip_context* ctx, const void* nodes, uint64_t 
     LT_HIP_CHECK(ctx, hipGetLastError());
     uint32_t bad = 0;
     LT_HIP_CHECK(ctx, hipMemcpyAsync(&bad, ctx->d_stats, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+    lap("mallocs, launches");
     LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ownOk = bad == 0;
+    lap("retile, pair and wide records");
   }
   if (!ownOk) {   // the scene then walks the caller's tree
-    for (void** p : {&ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_wide, &ctx->d_rank8}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    for (void** p : {&ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_wide, &ctx->d_rank8}) { ctx->pool.put(*p); *p = nullptr; }
   } else {
     ctx->n_nodes2 = n2;
     ctx->height2 = prep.own_height;
     ctx->n_wide = groups;
     ctx->wide_height = hw;
   }
-  lt_prep::release(prep);
+  lt_prep::release(prep, al);
   LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->retree_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  lap("pair and wide records");
+  lap("release");
   ctx->n_nodes = n_nodes;
   ctx->n_prims = n_prims;
   ctx->n_mats = n_mats;
@@ -763,7 +818,10 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
   // material is honoured).  LT_SCENE_ALWAYS_UPLOAD=1 turns the shortcut off.
   const uint64_t sizes[4] = {node_bytes, prim_bytes, material_bytes, light_bytes};
   const void* const bufs[4] = {nodes, prims, materials, lights};
+  const auto tHash = std::chrono::steady_clock::now();
   const SceneHash hash = known_hash ? *known_hash : hash_scene(bufs, sizes);
+  if (getenv("LT_DEBUG_SCENE_TIMING"))
+    fprintf(stderr, "[lt set_scene] %-28s %7.2f ms\n", known_hash ? "hash (known)" : "hash", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tHash).count());
   if (ctx->has_scene && memcmp(sizes, ctx->scene_sizes, sizeof(sizes)) == 0 && !getenv("LT_SCENE_ALWAYS_UPLOAD")) {
     if (hash == ctx->scene_hash) {
       ctx->scene_reused++;
@@ -845,11 +903,11 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
   LT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   LT_HIP_CHECK(ctx, hipDeviceSynchronize());
   free_scene(ctx);
-  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_nodes, node_bytes));
-  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_prims, prim_bytes));
-  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_tris, (size_t)n_prims * 48));
-  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_mats, material_bytes));
-  LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_lights, light_bytes));
+  LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_nodes, node_bytes));
+  LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_prims, prim_bytes));
+  LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_tris, (size_t)n_prims * 48));
+  LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_mats, material_bytes));
+  LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_lights, light_bytes));
   LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_nodes, nodes, node_bytes, hipMemcpyHostToDevice));
   LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_prims, prims, prim_bytes, hipMemcpyHostToDevice));
   LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_mats, materials, material_bytes, hipMemcpyHostToDevice));
@@ -888,8 +946,8 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
     if (h2 >= 0) {
       ctx->retree_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
       const uint32_t n2 = (uint32_t)own.size();
-      LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_nodes2, (size_t)n2 * 32));
-      LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_pairs2, (size_t)n2 * 64));
+      LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_nodes2, (size_t)n2 * 32));
+      LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_pairs2, (size_t)n2 * 64));
       LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_nodes2, own.data(), (size_t)n2 * 32, hipMemcpyHostToDevice));
       hipLaunchKernelGGL(lt_own_pair_kernel, dim3((n2 + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)ctx->d_nodes2,
                          (const float*)ctx->d_prims, (float4*)ctx->d_pairs2, n2);
@@ -907,9 +965,9 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
         for (int a = 0; a < 3; a++) lt_own16::frame(own[0].lo[a], own[0].hi[a], fr.O[a], fr.S[a]);
         const size_t records = (size_t)groups + n_prims + 1;
         void *d_children = nullptr, *d_groupOf = nullptr;
-        LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_wide, records * 64 + 64));   // (64 bytes in front: the grid, read by the walks themselves)
-        LT_HIP_CHECK(ctx, hipMalloc(&d_children, children.size() * 4));
-        LT_HIP_CHECK(ctx, hipMalloc(&d_groupOf, groupOf.size() * 4));
+        LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_wide, records * 64 + 64));   // (64 bytes in front: the grid, read by the walks themselves)
+        LT_HIP_CHECK(ctx, ctx->pool.get(&d_children, children.size() * 4));
+        LT_HIP_CHECK(ctx, ctx->pool.get(&d_groupOf, groupOf.size() * 4));
         const float head[16] = {0, 0, 0, 0, 0, 0, 0, 0, fr.O[0], fr.O[1], fr.O[2], 0.0f, fr.S[0], fr.S[1], fr.S[2], 0.0f};
         LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_wide, head, sizeof(head), hipMemcpyHostToDevice));
         LT_HIP_CHECK(ctx, hipMemcpy(d_children, children.data(), children.size() * 4, hipMemcpyHostToDevice));
@@ -925,13 +983,13 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
         uint32_t bad = 0;
         LT_HIP_CHECK(ctx, hipMemcpyAsync(&bad, ctx->d_stats, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
         LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_children);
-        (void)hipFree(d_groupOf);
+        ctx->pool.put(d_children);
+        ctx->pool.put(d_groupOf);
         ownOk = bad == 0;   // (a bound off the grid cannot happen for a grid sized from the root's box)
         lap("wide records (upload, kernels)");
       }
       if (!ownOk) {   // the scene then walks the caller's tree
-        for (void** p : {&ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_wide}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        for (void** p : {&ctx->d_nodes2, &ctx->d_pairs2, &ctx->d_wide}) { ctx->pool.put(*p); *p = nullptr; }
       } else {   // (the own tree's 32-byte form stays resident: an edit of the primitives alone re-makes the leaf records from it)
         ctx->n_nodes2 = n2;
         ctx->height2 = h2;
@@ -939,7 +997,7 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
         ctx->wide_height = hw;
         if (rankThread.joinable()) rankThread.join();
         if (!rankStarted || rankFailed) lt_retree::reference_order(nodes, n_nodes, n_prims, rank8);
-        LT_HIP_CHECK(ctx, hipMalloc(&ctx->d_rank8, rank8.size() * sizeof(uint32_t)));
+        LT_HIP_CHECK(ctx, ctx->pool.get(&ctx->d_rank8, rank8.size() * sizeof(uint32_t)));
         LT_HIP_CHECK(ctx, hipMemcpy(ctx->d_rank8, rank8.data(), rank8.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         lap("leaf order table (host, upload)");
       }

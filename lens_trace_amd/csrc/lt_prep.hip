@@ -71,6 +71,10 @@ __device__ __forceinline__ uint32_t max_child(uint32_t count, int heightLimit, u
   return cap < count ? (uint32_t)cap : count;
 }
 
+__device__ __forceinline__ float pick(const float* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
+__device__ __forceinline__ int picki(const int* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+
 struct Leaf { float4 a, b; float lo[3], hi[3], c[3]; };
 __device__ __forceinline__ void load_leaf(const float4* __restrict__ nd, uint32_t i, Leaf& l) {
   l.a = nd[2 * (size_t)i];
@@ -123,8 +127,9 @@ __global__ void k_check_prims(const int32_t* __restrict__ prims, uint32_t n_prim
   if (m < 0 || (uint32_t)m >= n_mats) atomicOr(&ctl[kCtlFlags], (uint32_t)kFlagPrimitives);
 }
 
-// end[i]: where the subtree of node i ends.  A left child ends where its sibling starts; a right child where its parent does.
-__global__ void k_subtree_ends(const float4* __restrict__ nd, uint32_t n, const uint32_t* __restrict__ parent, uint32_t* __restrict__ end,
+// up[i] = (parent word, end, off, axis) of node i, where end is where the subtree of node i ends: a left child ends where its
+// sibling starts, a right child where its parent does.  (One 16-byte record per step of the walk up in k_leaf_ranks.)
+__global__ void k_subtree_ends(const float4* __restrict__ nd, uint32_t n, const uint32_t* __restrict__ parent, uint4* __restrict__ up,
                                uint32_t* __restrict__ ctl) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -137,52 +142,50 @@ __global__ void k_subtree_ends(const float4* __restrict__ nd, uint32_t n, const 
     if (steps >= 64) { f |= kFlagTooDeep; ok = false; break; }
     x = p & ~kRight;
   }
+  const float4 b = nd[2 * (size_t)i + 1];
   if (ok) {
     e = x == 0 ? n : __float_as_uint(nd[2 * (size_t)parent[x] + 1].z);
-    const float4 b = nd[2 * (size_t)i + 1];
     const bool leaf = (__float_as_uint(b.w) & 0xffffu) != 0u;
     if (leaf ? e != i + 1 : !(__float_as_uint(b.z) < e)) f |= kFlagNotProper;
   }
-  end[i] = e;
+  up[i] = make_uint4(parent[i], e, __float_as_uint(b.z), (__float_as_uint(b.w) >> 16) & 3u);
   if (f) atomicOr(&ctl[kCtlFlags], f);
 }
 
-// Depth of every node, and for leaves: the eight positions of lt_retree::reference_order and the leaf's place in the caller's
-// pre-order (= the position for the all-positive octant), which is the order the host build starts from.
-__global__ void k_leaf_ranks(const float4* __restrict__ nd, uint32_t n, uint32_t n_prims, const uint32_t* __restrict__ parent,
-                             const uint32_t* __restrict__ end, uint32_t* __restrict__ rank8, uint32_t* __restrict__ order,
-                             uint32_t* __restrict__ ctl) {
+// For leaves: the depth, the eight positions of lt_retree::reference_order and the leaf's place in the caller's pre-order (= the
+// position for the all-positive octant), which is the order the host build starts from.
+__global__ void k_leaf_ranks(const float4* __restrict__ nd, uint32_t n, uint32_t n_prims, const uint4* __restrict__ up,
+                             uint32_t* __restrict__ rank8, uint32_t* __restrict__ order, uint32_t* __restrict__ ctl) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t depth = 0, f = 0;
   if (i < n) {
     const float4 b = nd[2 * (size_t)i + 1];
-    const bool leaf = (__float_as_uint(b.w) & 0xffffu) != 0u;
-    uint32_t base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t c = i;
-    while (c != 0) {
-      const uint32_t pw = parent[c];
-      if (pw == kNone) { f |= kFlagNotProper; break; }
-      if (++depth > 64) { f |= kFlagTooDeep; break; }
-      const uint32_t p = pw & ~kRight, right = pw >> 31;
-      if (leaf) {
-        const float4 pb = nd[2 * (size_t)p + 1];
-        const uint32_t poff = __float_as_uint(pb.z), paxis = (__float_as_uint(pb.w) >> 16) & 3u;
+    const bool leaf = (__float_as_uint(b.w) & 0xffffu) != 0u;   // (the deepest node is a leaf; k_subtree_ends has seen to it that every node has a parent)
+    if (leaf) {
+      uint32_t base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t c = i, pw = up[i].x;
+      while (c != 0) {
+        if (pw == kNone) { f |= kFlagNotProper; break; }
+        if (++depth > 64) { f |= kFlagTooDeep; break; }
+        const uint32_t p = pw & ~kRight, right = pw >> 31;
+        const uint4 rec = up[p];
         // under the right child: the left subtree's leaves come first where the direction is positive on the parent's axis;
         // under the left child: the right subtree's where it is negative
-        const uint32_t amount = right ? (poff - p) / 2u : (end[p] - poff + 1u) / 2u;
+        const uint32_t amount = right ? (rec.z - p) / 2u : (rec.y - rec.z + 1u) / 2u;
         for (uint32_t o = 0; o < 8; o++)
-          if (((o >> paxis) & 1u) != right) base[o] += amount;
+          if (((o >> rec.w) & 1u) != right) base[o] += amount;
+        c = p;
+        pw = rec.x;
       }
-      c = p;
-    }
-    if (leaf && f == 0) {
-      const uint32_t prim = __float_as_uint(b.z);
-      if (prim < n_prims) {
-        uint4* r = (uint4*)(rank8 + 8 * (size_t)prim);
-        r[0] = make_uint4(base[0], base[1], base[2], base[3]);
-        r[1] = make_uint4(base[4], base[5], base[6], base[7]);
+      if (f == 0) {
+        const uint32_t prim = __float_as_uint(b.z);
+        if (prim < n_prims) {
+          uint4* r = (uint4*)(rank8 + 8 * (size_t)prim);
+          r[0] = make_uint4(base[0], base[1], base[2], base[3]);
+          r[1] = make_uint4(base[4], base[5], base[6], base[7]);
+        }
+        if (base[0] < (n + 1) / 2) order[base[0]] = i;
       }
-      if (base[0] < (n + 1) / 2) order[base[0]] = i;
     }
   }
   const uint32_t deepest = wave_max_u(f ? 0u : depth);
@@ -277,6 +280,12 @@ __device__ void emit_child(Range c, Range* __restrict__ nextBig, Range* __restri
 }
 
 // ------------------------------------------------------------------------------------------ at most 64 leaves: the whole subtree
+// Ranges of at most kSmall leaves -- seven in eight of a subtree's nodes -- do not fill bins: a plane that matters is the plane
+// behind some leaf's own bin (any other plane has the same two sides as the nearest such plane below it, hence the same cost,
+// and the host's sweep keeps the first of equals), so every leaf prices the three planes behind its own bins against the
+// range's leaves, read lane by lane.
+constexpr uint32_t kSmall = 8;
+
 __global__ __launch_bounds__(256) void k_tiny(const float4* __restrict__ nd, const uint32_t* __restrict__ order, const Range* __restrict__ list,
                                                const uint32_t* __restrict__ counts, float4* __restrict__ out, int heightLimit,
                                                uint32_t* __restrict__ ctl) {
@@ -290,6 +299,8 @@ __global__ __launch_bounds__(256) void k_tiny(const float4* __restrict__ nd, con
   Leaf l;
   const uint32_t leaf = has ? order[rg.start + lane] : 0u;
   load_leaf(nd, leaf, l);
+  uint32_t olo[3], ohi[3], oc[3];
+  for (int k = 0; k < 3; k++) { olo[k] = ordered(l.lo[k]); ohi[k] = ordered(l.hi[k]); oc[k] = ordered(l.c[k]); }
   uint32_t pos = lane;   // relative position; lanes without a leaf keep their own (the positions stay a permutation of 0..63)
   uint32_t* bins = s_bins[wave];
   uint4* stack = s_stack[wave];
@@ -303,46 +314,103 @@ __global__ __launch_bounds__(256) void k_tiny(const float4* __restrict__ nd, con
     const uint4 top = stack[--sp];
     const uint32_t s = top.x, e = top.y, node = top.z, depth = top.w, cnt = e - s;
     const bool in = has && pos >= s && pos < e;
-    deepest = max(deepest, depth);
-    if (cnt == 1) {
-      if (in) { out[2 * (size_t)node] = l.a; out[2 * (size_t)node + 1] = l.b; }
-      continue;
-    }
+    const uint64_t inMask = __ballot(in);
+    deepest = max(deepest, depth + 1);   // (two leaves at least: there is a level below)
     float lo[3], hi[3], cmin[3], cmax[3], d[3], scale[3];
+    if (cnt <= kSmall) {
+      uint32_t a[12];
+      for (int k = 0; k < 12; k++) a[k] = (k % 6) < 3 ? kMinIdentity : kMaxIdentity;
+      for (uint64_t m = inMask; m; m &= m - 1) {
+        const int src = __builtin_ctzll(m);
+        for (int k = 0; k < 3; k++) {
+          a[k] = min(a[k], read_lane(olo[k], src));
+          a[3 + k] = max(a[3 + k], read_lane(ohi[k], src));
+          const uint32_t c = read_lane(oc[k], src);
+          a[6 + k] = min(a[6 + k], c);
+          a[9 + k] = max(a[9 + k], c);
+        }
+      }
+      for (int k = 0; k < 3; k++) { lo[k] = unordered(a[k]); hi[k] = unordered(a[3 + k]); cmin[k] = unordered(a[6 + k]); cmax[k] = unordered(a[9 + k]); }
+    } else {
+      for (int k = 0; k < 3; k++) {
+        lo[k] = unordered(wave_min_u(in ? olo[k] : kMinIdentity));
+        hi[k] = unordered(wave_max_u(in ? ohi[k] : kMaxIdentity));
+        cmin[k] = unordered(wave_min_u(in ? oc[k] : kMinIdentity));
+        cmax[k] = unordered(wave_max_u(in ? oc[k] : kMaxIdentity));
+      }
+    }
+    int myBin[3];
     for (int k = 0; k < 3; k++) {
-      lo[k] = unordered(wave_min_u(in ? ordered(l.lo[k]) : kMinIdentity));
-      hi[k] = unordered(wave_max_u(in ? ordered(l.hi[k]) : kMaxIdentity));
-      cmin[k] = unordered(wave_min_u(in ? ordered(l.c[k]) : kMinIdentity));
-      cmax[k] = unordered(wave_max_u(in ? ordered(l.c[k]) : kMaxIdentity));
       d[k] = __fsub_rn(cmax[k], cmin[k]);
       scale[k] = bin_scale(d[k]);
+      myBin[k] = bin_of(l.c[k], cmin[k], scale[k]);
     }
     int dim = largest_extent(d);
     uint32_t left = cnt / 2;
     bool split = false, pred = false;
     const uint32_t maxChild = max_child(cnt, heightLimit, depth);
     if (cnt > 2 && maxChild >= (cnt + 1) / 2) {
-      clear_bins(bins);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (in) bin_leaf(bins, l, cmin, scale, d);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const Split sp2 = sah_eval(bins, d, maxChild);
-      if (sp2.dim >= 0) {
+      int bestDim = -1, bestBin = -1;
+      if (cnt <= kSmall) {
+        float cost = __builtin_inff();
+        uint32_t idx = kNone;
+        for (int a = 0; a < 3; a++) {
+          if (!(d[a] > 0.0f)) continue;
+          uint32_t L[6] = {kMinIdentity, kMinIdentity, kMinIdentity, kMaxIdentity, kMaxIdentity, kMaxIdentity};
+          uint32_t R[6] = {kMinIdentity, kMinIdentity, kMinIdentity, kMaxIdentity, kMaxIdentity, kMaxIdentity};
+          uint32_t nL = 0;
+          for (uint64_t m = inMask; m; m &= m - 1) {
+            const int src = __builtin_ctzll(m);
+            const bool isL = (int)read_lane((uint32_t)myBin[a], src) <= myBin[a];
+            nL += isL ? 1u : 0u;
+            for (int k = 0; k < 3; k++) {
+              const uint32_t vl = read_lane(olo[k], src), vh = read_lane(ohi[k], src);
+              L[k] = isL ? min(L[k], vl) : L[k];
+              L[3 + k] = isL ? max(L[3 + k], vh) : L[3 + k];
+              R[k] = isL ? R[k] : min(R[k], vl);
+              R[3 + k] = isL ? R[3 + k] : max(R[3 + k], vh);
+            }
+          }
+          const uint32_t nR = cnt - nL;
+          if (in && myBin[a] < kBins - 1 && nR != 0 && nL <= maxChild && nR <= maxChild) {
+            float flo[3], fhi[3], glo[3], ghi[3];
+            for (int k = 0; k < 3; k++) { flo[k] = unordered(L[k]); fhi[k] = unordered(L[3 + k]); glo[k] = unordered(R[k]); ghi[k] = unordered(R[3 + k]); }
+            const float c = __fadd_rn(__fmul_rn(half_area(flo, fhi), (float)nL), __fmul_rn(half_area(glo, ghi), (float)nR));
+            const uint32_t i = (uint32_t)a * 32u + (uint32_t)myBin[a];
+            if (c < cost || (c == cost && i < idx)) { cost = c; idx = i; }
+          }
+        }
+        for (int m = 32; m; m >>= 1) {
+          const float oc2 = __shfl_xor(cost, m);
+          const uint32_t oi = (uint32_t)__shfl_xor((int)idx, m);
+          if (oc2 < cost || (oc2 == cost && oi < idx)) { cost = oc2; idx = oi; }
+        }
+        if (cost < 3.402823466e+38f && idx != kNone) { bestDim = (int)(idx >> 5); bestBin = (int)(idx & 31u); }
+      } else {
+        clear_bins(bins);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (in) bin_leaf(bins, l, cmin, scale, d);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const Split sp2 = sah_eval(bins, d, maxChild);
+        bestDim = sp2.dim;
+        bestBin = sp2.bin;
+      }
+      if (bestDim >= 0) {
         split = true;
-        dim = sp2.dim;
-        left = sp2.left;
-        pred = bin_of(l.c[dim], cmin[dim], scale[dim]) <= sp2.bin;
+        dim = bestDim;
+        pred = picki(myBin, dim) <= bestBin;
+        left = (uint32_t)__popcll(__ballot(in && pred));
       }
     }
     if (!split) {
-      if (d[dim] > 0.0f) {   // the cnt / 2 smallest (centroid, leaf index) go left
-        const uint32_t kh = ordered(l.c[dim]);
+      if (pick(d, dim) > 0.0f) {   // the cnt / 2 smallest (centroid, leaf index) go left
+        const uint32_t kh = dim == 0 ? oc[0] : (dim == 1 ? oc[1] : oc[2]);
         uint32_t rank = 0;
-        for (uint64_t m = __ballot(in); m; m &= m - 1) {
+        for (uint64_t m = inMask; m; m &= m - 1) {
           const int src = __builtin_ctzll(m);
-          const uint32_t oh = (uint32_t)__shfl((int)kh, src), ol = (uint32_t)__shfl((int)leaf, src);
+          const uint32_t oh = read_lane(kh, src), ol = read_lane(leaf, src);
           rank += (oh < kh || (oh == kh && ol < leaf)) ? 1u : 0u;
         }
         pred = rank < left;
@@ -358,13 +426,20 @@ __global__ __launch_bounds__(256) void k_tiny(const float4* __restrict__ nd, con
     if ((uint32_t)__popcll(L) != left || left == 0 || left >= cnt) bad = 1;
     if (bad) break;
     if (in) pos = pred ? s + (uint32_t)__popcll(L & below) : s + left + (uint32_t)__popcll(Rm & below);
-    const uint32_t rightNode = node + 2u * left;
+    const uint32_t rightNode = node + 2u * left, right = cnt - left;
+    // a child of one leaf is written by the lane that holds it; larger children wait on the stack
+    if (in && ((left == 1 && pos == s) || (right == 1 && pos == s + left))) {
+      const uint32_t at = pos == s ? node + 1 : rightNode;
+      out[2 * (size_t)at] = l.a;
+      out[2 * (size_t)at + 1] = l.b;
+    }
     if (lane == 0) {
       store_interior(out, node, lo, hi, rightNode, dim);
-      stack[sp] = make_uint4(s + left, e, rightNode, depth + 1);
-      stack[sp + 1] = make_uint4(s, s + left, node + 1, depth + 1);
+      uint32_t q = sp;
+      if (right > 1) stack[q++] = make_uint4(s + left, e, rightNode, depth + 1);
+      if (left > 1) stack[q] = make_uint4(s, s + left, node + 1, depth + 1);
     }
-    sp += 2;
+    sp += (right > 1 ? 1 : 0) + (left > 1 ? 1 : 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (sp > 64) { bad = 1; break; }
   }
@@ -372,6 +447,30 @@ __global__ __launch_bounds__(256) void k_tiny(const float4* __restrict__ nd, con
     atomicMax(&ctl[kCtlOwnHeight], deepest);
     if (bad) atomicOr(&ctl[kCtlFlags], (uint32_t)kFlagInternal);
   }
+}
+
+// four leaves per lane and round of a looping wavefront: the indices first, then the nodes
+struct WaveLeaves { uint32_t leaf[4]; float4 a[4], b[4]; };
+__device__ __forceinline__ void load_wave(const float4* __restrict__ nd, const uint32_t* __restrict__ order, uint32_t base, uint32_t end, WaveLeaves& wl) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t i = base + (uint32_t)j * 64u + lane_id();
+    wl.leaf[j] = i < end ? order[i] : kNone;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t at = wl.leaf[j] != kNone ? wl.leaf[j] : 0u;
+    wl.a[j] = nd[2 * (size_t)at];
+    wl.b[j] = nd[2 * (size_t)at + 1];
+  }
+}
+template <class LEAVES>
+__device__ __forceinline__ void leaf_of(const LEAVES& cl, int j, Leaf& l) {
+  l.a = cl.a[j];
+  l.b = cl.b[j];
+  l.lo[0] = l.a.x; l.lo[1] = l.a.y; l.lo[2] = l.a.z;
+  l.hi[0] = l.a.w; l.hi[1] = l.b.x; l.hi[2] = l.b.y;
+  for (int k = 0; k < 3; k++) l.c[k] = __fadd_rn(__fmul_rn(0.5f, l.lo[k]), __fmul_rn(0.5f, l.hi[k]));
 }
 
 // ------------------------------------------------------------------------------------------ one wavefront per range, looping
@@ -388,14 +487,20 @@ __global__ __launch_bounds__(256) void k_mid(const float4* __restrict__ nd, cons
   // bounds
   uint32_t olo[3] = {kMinIdentity, kMinIdentity, kMinIdentity}, ohi[3] = {kMaxIdentity, kMaxIdentity, kMaxIdentity};
   uint32_t ocmin[3] = {kMinIdentity, kMinIdentity, kMinIdentity}, ocmax[3] = {kMaxIdentity, kMaxIdentity, kMaxIdentity};
-  for (uint32_t i = rg.start + lane; i < rg.end; i += 64) {
-    Leaf l;
-    load_leaf(nd, orderIn[i], l);
-    for (int k = 0; k < 3; k++) {
-      olo[k] = min(olo[k], ordered(l.lo[k]));
-      ohi[k] = max(ohi[k], ordered(l.hi[k]));
-      ocmin[k] = min(ocmin[k], ordered(l.c[k]));
-      ocmax[k] = max(ocmax[k], ordered(l.c[k]));
+  for (uint32_t base = rg.start; base < rg.end; base += 256) {
+    WaveLeaves wl;
+    load_wave(nd, orderIn, base, rg.end, wl);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (wl.leaf[j] == kNone) continue;
+      Leaf l;
+      leaf_of(wl, j, l);
+      for (int k = 0; k < 3; k++) {
+        olo[k] = min(olo[k], ordered(l.lo[k]));
+        ohi[k] = max(ohi[k], ordered(l.hi[k]));
+        ocmin[k] = min(ocmin[k], ordered(l.c[k]));
+        ocmax[k] = max(ocmax[k], ordered(l.c[k]));
+      }
     }
   }
   float lo[3], hi[3], cmin[3], cmax[3], d[3], scale[3];
@@ -416,17 +521,23 @@ __global__ __launch_bounds__(256) void k_mid(const float4* __restrict__ nd, cons
     clear_bins(bins);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (uint32_t i = rg.start + lane; i < rg.end; i += 64) {
-      Leaf l;
-      load_leaf(nd, orderIn[i], l);
-      bin_leaf(bins, l, cmin, scale, d);
+    for (uint32_t base = rg.start; base < rg.end; base += 256) {
+      WaveLeaves wl;
+      load_wave(nd, orderIn, base, rg.end, wl);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (wl.leaf[j] == kNone) continue;
+        Leaf l;
+        leaf_of(wl, j, l);
+        bin_leaf(bins, l, cmin, scale, d);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const Split sp = sah_eval(bins, d, maxChild);
     if (sp.dim >= 0) { mode = 0; dim = sp.dim; bestBin = sp.bin; left = sp.left; }
   }
-  if (mode != 0 && d[dim] > 0.0f) {
+  if (mode != 0 && pick(d, dim) > 0.0f) {
     // the key of rank cnt / 2 among (ordered centroid, leaf index), eight bits at a time (the histogram lives where the bins did)
     mode = 1;
     uint32_t k = cnt / 2;
@@ -439,7 +550,7 @@ __global__ __launch_bounds__(256) void k_mid(const float4* __restrict__ nd, cons
         Leaf l;
         const uint32_t leaf = orderIn[i];
         load_leaf(nd, leaf, l);
-        const uint64_t key = ((uint64_t)ordered(l.c[dim]) << 32) | leaf;
+        const uint64_t key = ((uint64_t)ordered(pick(l.c, dim)) << 32) | leaf;
         if ((key & mask) == (pivot & mask)) atomicAdd(&bins[(uint32_t)(key >> shift) & 255u], 1u);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -477,25 +588,31 @@ __global__ __launch_bounds__(256) void k_mid(const float4* __restrict__ nd, cons
   // stable partition into the next level's order
   const uint32_t rightNode = rg.node + 2u * left, right = cnt - left;
   uint32_t doneL = 0, doneR = 0;
-  for (uint32_t base = rg.start; base < rg.end; base += 64) {
-    const uint32_t i = base + lane;
-    const bool in = i < rg.end;
-    Leaf l;
-    const uint32_t leaf = in ? orderIn[i] : 0u;
-    load_leaf(nd, leaf, l);
-    bool pred;
-    if (mode == 0) pred = bin_of(l.c[dim], cmin[dim], scale[dim]) <= bestBin;
-    else if (mode == 1) pred = (((uint64_t)ordered(l.c[dim]) << 32) | leaf) < pivot;
-    else pred = i - rg.start < left;
-    const uint64_t mL = __ballot(in && pred), mR = __ballot(in && !pred), below = (1ull << lane) - 1ull;
-    if (in) {
-      const uint32_t to = pred ? rg.start + doneL + (uint32_t)__popcll(mL & below) : rg.start + left + doneR + (uint32_t)__popcll(mR & below);
-      orderOut[to] = leaf;
-      if (left == 1 && to == rg.start) { out[2 * (size_t)(rg.node + 1)] = l.a; out[2 * (size_t)(rg.node + 1) + 1] = l.b; }
-      if (right == 1 && to == rg.start + left) { out[2 * (size_t)rightNode] = l.a; out[2 * (size_t)rightNode + 1] = l.b; }
+  const float cminD = pick(cmin, dim), scaleD = pick(scale, dim);
+  for (uint32_t base = rg.start; base < rg.end; base += 256) {
+    WaveLeaves wl;
+    load_wave(nd, orderIn, base, rg.end, wl);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t i = base + (uint32_t)j * 64u + lane, leaf = wl.leaf[j];
+      const bool in = leaf != kNone;
+      Leaf l;
+      leaf_of(wl, j, l);
+      const float cD = pick(l.c, dim);
+      bool pred;
+      if (mode == 0) pred = bin_of(cD, cminD, scaleD) <= bestBin;
+      else if (mode == 1) pred = (((uint64_t)ordered(cD) << 32) | leaf) < pivot;
+      else pred = i - rg.start < left;
+      const uint64_t mL = __ballot(in && pred), mR = __ballot(in && !pred), below = (1ull << lane) - 1ull;
+      if (in) {
+        const uint32_t to = pred ? rg.start + doneL + (uint32_t)__popcll(mL & below) : rg.start + left + doneR + (uint32_t)__popcll(mR & below);
+        orderOut[to] = leaf;
+        if (left == 1 && to == rg.start) { out[2 * (size_t)(rg.node + 1)] = l.a; out[2 * (size_t)(rg.node + 1) + 1] = l.b; }
+        if (right == 1 && to == rg.start + left) { out[2 * (size_t)rightNode] = l.a; out[2 * (size_t)rightNode + 1] = l.b; }
+      }
+      doneL += (uint32_t)__popcll(mL);
+      doneR += (uint32_t)__popcll(mR);
     }
-    doneL += (uint32_t)__popcll(mL);
-    doneR += (uint32_t)__popcll(mR);
   }
   if (lane == 0) {
     if (doneL != left) atomicOr(&ctl[kCtlFlags], (uint32_t)kFlagInternal);
@@ -540,16 +657,36 @@ __device__ __forceinline__ bool chunk_of(const Range* __restrict__ list, const u
   return true;
 }
 
+// the leaves of a chunk, eight per thread: all indices first, then all nodes (two rounds of memory latency, not sixteen)
+struct ChunkLeaves { uint32_t leaf[8]; float4 a[8], b[8]; };
+__device__ __forceinline__ void load_chunk(const float4* __restrict__ nd, const uint32_t* __restrict__ order, uint32_t s, uint32_t e, ChunkLeaves& cl) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t i = s + (uint32_t)j * 256u + threadIdx.x;
+    cl.leaf[j] = i < e ? order[i] : kNone;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t at = cl.leaf[j] != kNone ? cl.leaf[j] : 0u;
+    cl.a[j] = nd[2 * (size_t)at];
+    cl.b[j] = nd[2 * (size_t)at + 1];
+  }
+}
 __global__ __launch_bounds__(256) void k_big_bounds(const float4* __restrict__ nd, const uint32_t* __restrict__ order, const Range* __restrict__ list,
                                                      const uint32_t* __restrict__ chunkBase, const uint32_t* __restrict__ chunkRange,
                                                      uint32_t* __restrict__ acc, const uint32_t* __restrict__ ctl) {
   ChunkOf c;
   if (!chunk_of(list, chunkBase, chunkRange, ctl, c)) return;
+  __shared__ uint32_t s_v[4][12];
   uint32_t v[12];
   for (int k = 0; k < 12; k++) v[k] = (k % 6) < 3 ? kMinIdentity : kMaxIdentity;
-  for (uint32_t i = c.s + threadIdx.x; i < c.e; i += 256) {
+  ChunkLeaves cl;
+  load_chunk(nd, order, c.s, c.e, cl);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if (cl.leaf[j] == kNone) continue;
     Leaf l;
-    load_leaf(nd, order[i], l);
+    leaf_of(cl, j, l);
     for (int k = 0; k < 3; k++) {
       v[k] = min(v[k], ordered(l.lo[k]));
       v[3 + k] = max(v[3 + k], ordered(l.hi[k]));
@@ -558,11 +695,14 @@ __global__ __launch_bounds__(256) void k_big_bounds(const float4* __restrict__ n
     }
   }
   for (int k = 0; k < 12; k++) {
-    const bool isMin = (k % 6) < 3;
-    const uint32_t w = isMin ? wave_min_u(v[k]) : wave_max_u(v[k]);
-    if (lane_id() == 0) {
-      if (isMin) atomicMin(&acc[12 * (size_t)c.r + k], w); else atomicMax(&acc[12 * (size_t)c.r + k], w);
-    }
+    const uint32_t w = (k % 6) < 3 ? wave_min_u(v[k]) : wave_max_u(v[k]);
+    if (lane_id() == 0) s_v[threadIdx.x >> 6][k] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const uint32_t k = threadIdx.x;
+    if ((k % 6) < 3) atomicMin(&acc[12 * (size_t)c.r + k], min(min(s_v[0][k], s_v[1][k]), min(s_v[2][k], s_v[3][k])));
+    else atomicMax(&acc[12 * (size_t)c.r + k], max(max(s_v[0][k], s_v[1][k]), max(s_v[2][k], s_v[3][k])));
   }
 }
 
@@ -587,10 +727,16 @@ __global__ __launch_bounds__(256) void k_big_bins(const float4* __restrict__ nd,
   Bounds b;
   read_bounds(acc, c.r, b);
   __syncthreads();
-  for (uint32_t i = c.s + threadIdx.x; i < c.e; i += 256) {
-    Leaf l;
-    load_leaf(nd, order[i], l);
-    bin_leaf(s_bins, l, b.cmin, b.scale, b.d);
+  {
+    ChunkLeaves cl;
+    load_chunk(nd, order, c.s, c.e, cl);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (cl.leaf[j] == kNone) continue;
+      Leaf l;
+      leaf_of(cl, j, l);
+      bin_leaf(s_bins, l, b.cmin, b.scale, b.d);
+    }
   }
   __syncthreads();
   uint32_t* g = bins + (size_t)c.r * kRangeBins;
@@ -635,10 +781,17 @@ __global__ __launch_bounds__(256) void k_big_split(const float4* __restrict__ nd
     return;
   }
   uint32_t mine = 0;
-  for (uint32_t i = c.s + threadIdx.x; i < c.e; i += 256) {
-    Leaf l;
-    load_leaf(nd, order[i], l);
-    mine += bin_of(l.c[sp.dim], b.cmin[sp.dim], b.scale[sp.dim]) <= sp.bin ? 1u : 0u;
+  {
+    const float cminD = pick(b.cmin, sp.dim), scaleD = pick(b.scale, sp.dim);
+    ChunkLeaves cl;
+    load_chunk(nd, order, c.s, c.e, cl);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (cl.leaf[j] == kNone) continue;
+      Leaf l;
+      leaf_of(cl, j, l);
+      mine += bin_of(pick(l.c, sp.dim), cminD, scaleD) <= sp.bin ? 1u : 0u;
+    }
   }
   mine = wave_sum_u(mine);
   if (lane_id() == 0) s_count[threadIdx.x >> 6] = mine;
@@ -646,7 +799,7 @@ __global__ __launch_bounds__(256) void k_big_split(const float4* __restrict__ nd
   if (threadIdx.x == 0) {
     chunkLeft[blockIdx.x] = s_count[0] + s_count[1] + s_count[2] + s_count[3];
     if (first) {
-      SplitRec rec{sp.dim, sp.bin, b.cmin[sp.dim], b.scale[sp.dim], sp.left, 0u, 0u, 0u};
+      SplitRec rec{sp.dim, sp.bin, pick(b.cmin, sp.dim), pick(b.scale, sp.dim), sp.left, 0u, 0u, 0u};
       splits[c.r] = rec;
       const uint32_t rightNode = c.rg.node + 2u * sp.left;
       store_interior(out, c.rg.node, b.lo, b.hi, rightNode, sp.dim);
@@ -661,7 +814,7 @@ __global__ __launch_bounds__(256) void k_big_scatter(const float4* __restrict__ 
                                                       const Range* __restrict__ list, const uint32_t* __restrict__ chunkBase,
                                                       const uint32_t* __restrict__ chunkRange, const SplitRec* __restrict__ splits,
                                                       const uint32_t* __restrict__ chunkLeft, float4* __restrict__ out, uint32_t* __restrict__ ctl) {
-  __shared__ uint32_t s_sum[4], s_l[4], s_r[4];
+  __shared__ uint32_t s_sum[4], s_cl[8][4], s_cr[8][4];
   ChunkOf c;
   if (!chunk_of(list, chunkBase, chunkRange, ctl, c)) return;
   const SplitRec sp = splits[c.r];
@@ -674,33 +827,43 @@ __global__ __launch_bounds__(256) void k_big_scatter(const float4* __restrict__ 
   __syncthreads();
   before = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
   const uint32_t cnt = c.rg.end - c.rg.start, right = cnt - sp.left, rightNode = c.rg.node + 2u * sp.left;
-  uint32_t toL = c.rg.start + before, toR = c.rg.start + sp.left + (c.s - c.rg.start - before);
+  const uint32_t toL = c.rg.start + before, toR = c.rg.start + sp.left + (c.s - c.rg.start - before);
   const uint32_t wave = threadIdx.x >> 6;
-  for (uint32_t base = c.s; base < c.e; base += 256) {
-    const uint32_t i = base + threadIdx.x;
-    const bool in = i < c.e;
+  // the chunk in rounds of 256 leaves: where a leaf goes = the leaves of its side in earlier rounds, in earlier wavefronts of
+  // its round, in lower lanes of its wavefront
+  ChunkLeaves cl;
+  load_chunk(nd, orderIn, c.s, c.e, cl);
+  bool pred[8];
+  uint64_t mL[8], mR[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const bool in = cl.leaf[j] != kNone;
     Leaf l;
-    const uint32_t leaf = in ? orderIn[i] : 0u;
-    load_leaf(nd, leaf, l);
-    const bool pred = bin_of(l.c[sp.dim], sp.cmin, sp.scale) <= sp.bin;
-    const uint64_t mL = __ballot(in && pred), mR = __ballot(in && !pred), below = (1ull << lane_id()) - 1ull;
-    __syncthreads();   // (the counts of the previous round have been read)
-    if (lane_id() == 0) { s_l[wave] = (uint32_t)__popcll(mL); s_r[wave] = (uint32_t)__popcll(mR); }
-    __syncthreads();
+    leaf_of(cl, j, l);
+    pred[j] = bin_of(pick(l.c, sp.dim), sp.cmin, sp.scale) <= sp.bin;
+    mL[j] = __ballot(in && pred[j]);
+    mR[j] = __ballot(in && !pred[j]);
+    if (lane_id() == 0) { s_cl[j][wave] = (uint32_t)__popcll(mL[j]); s_cr[j][wave] = (uint32_t)__popcll(mR[j]); }
+  }
+  __syncthreads();
+  uint32_t runL = 0, runR = 0;
+  const uint64_t below = (1ull << lane_id()) - 1ull;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
     uint32_t wl = 0, wr = 0, allL = 0, allR = 0;
     for (uint32_t q = 0; q < 4; q++) {
-      if (q < wave) { wl += s_l[q]; wr += s_r[q]; }
-      allL += s_l[q];
-      allR += s_r[q];
+      if (q < wave) { wl += s_cl[j][q]; wr += s_cr[j][q]; }
+      allL += s_cl[j][q];
+      allR += s_cr[j][q];
     }
-    if (in) {
-      const uint32_t to = pred ? toL + wl + (uint32_t)__popcll(mL & below) : toR + wr + (uint32_t)__popcll(mR & below);
-      orderOut[to] = leaf;
-      if (sp.left == 1 && to == c.rg.start) { out[2 * (size_t)(c.rg.node + 1)] = l.a; out[2 * (size_t)(c.rg.node + 1) + 1] = l.b; }
-      if (right == 1 && to == c.rg.start + sp.left) { out[2 * (size_t)rightNode] = l.a; out[2 * (size_t)rightNode + 1] = l.b; }
+    if (cl.leaf[j] != kNone) {
+      const uint32_t to = pred[j] ? toL + runL + wl + (uint32_t)__popcll(mL[j] & below) : toR + runR + wr + (uint32_t)__popcll(mR[j] & below);
+      orderOut[to] = cl.leaf[j];
+      if (sp.left == 1 && to == c.rg.start) { out[2 * (size_t)(c.rg.node + 1)] = cl.a[j]; out[2 * (size_t)(c.rg.node + 1) + 1] = cl.b[j]; }
+      if (right == 1 && to == c.rg.start + sp.left) { out[2 * (size_t)rightNode] = cl.a[j]; out[2 * (size_t)rightNode + 1] = cl.b[j]; }
     }
-    toL += allL;
-    toR += allR;
+    runL += allL;
+    runR += allR;
   }
   (void)ctl;
 }
@@ -814,25 +977,25 @@ struct Carver {
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 
-void release(Out& out) {
+void release(Out& out, const Allocator& al) {
   for (void** p : {&out.d_nodes2, &out.d_rank8, &out.d_children, &out.d_groupOf}) {
-    if (*p) (void)hipFree(*p);
+    if (*p) al.put(al.self, *p);
     *p = nullptr;
   }
 }
 
-#define LT_PREP_CHECK(expr)                 \
-  do {                                      \
-    const hipError_t e_ = (expr);           \
-    if (e_ != hipSuccess) {                 \
-      if (scratch) (void)hipFree(scratch);  \
-      release(out);                         \
-      return e_;                            \
-    }                                       \
+#define LT_PREP_CHECK(expr)                      \
+  do {                                           \
+    const hipError_t e_ = (expr);                \
+    if (e_ != hipSuccess) {                      \
+      if (scratch) al.put(al.self, scratch);     \
+      release(out, al);                          \
+      return e_;                                 \
+    }                                            \
   } while (0)
 
 hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint32_t n_prims, uint32_t n_mats, int maxHeight, int slack,
-               bool ownSplits, hipStream_t stream, Out& out) {
+               bool ownSplits, hipStream_t stream, const Allocator& al, Out& out) {
   static_assert(kBins == 32, "the device build scans 32 bins with 32 lanes");
   out = Out{};
   uint8_t* scratch = nullptr;
@@ -848,7 +1011,7 @@ hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint3
   const int maxLevels = 66;
   const uint32_t maxBig = n / kChunk + 2, maxMid = n / 32 + 2, maxTiny = n / 2 + 2, maxChunks = n / kChunk + maxBig + 2;
   Carver cv;
-  const size_t o_parent = cv.take((size_t)N * 4), o_end = cv.take((size_t)N * 4), o_seen = cv.take(((size_t)n_prims + 31) / 32 * 4);
+  const size_t o_parent = cv.take((size_t)N * 4), o_up = cv.take((size_t)N * 16), o_seen = cv.take(((size_t)n_prims + 31) / 32 * 4);
   const size_t o_order0 = cv.take((size_t)n * 4), o_order1 = cv.take((size_t)n * 4);
   const size_t o_big0 = cv.take((size_t)maxBig * 16), o_big1 = cv.take((size_t)maxBig * 16);
   const size_t o_mid0 = cv.take((size_t)maxMid * 16), o_mid1 = cv.take((size_t)maxMid * 16);
@@ -857,7 +1020,7 @@ hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint3
   const size_t o_chunkBase = cv.take((size_t)(maxBig + 1) * 4), o_chunkRange = cv.take((size_t)maxChunks * 4), o_chunkLeft = cv.take((size_t)maxChunks * 4);
   const size_t o_acc = cv.take((size_t)maxBig * 12 * 4), o_bins = cv.take((size_t)maxBig * kRangeBins * 4), o_splits = cv.take((size_t)maxBig * sizeof(SplitRec));
   const size_t o_front0 = cv.take((size_t)n * 4), o_front1 = cv.take((size_t)n * 4), o_sums = cv.take(((size_t)(2 * n) / 2048 + 2) * 4);
-  LT_PREP_CHECK(hipMalloc((void**)&scratch, cv.size));
+  LT_PREP_CHECK(al.get(al.self, (void**)&scratch, cv.size));
   auto at = [&](size_t off) { return scratch + off; };
   uint32_t* ctl = (uint32_t*)at(o_ctl);
   uint32_t* counts = (uint32_t*)at(o_counts);
@@ -865,7 +1028,7 @@ hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint3
   const double t0 = now_ms();
 
   // ---- checks, leaf order table, the leaves in the caller's pre-order
-  LT_PREP_CHECK(hipMalloc(&out.d_rank8, (size_t)n_prims * 32));
+  LT_PREP_CHECK(al.get(al.self, &out.d_rank8, (size_t)n_prims * 32));
   LT_PREP_CHECK(hipMemsetAsync(at(o_parent), 0xff, (size_t)N * 4, stream));
   LT_PREP_CHECK(hipMemsetAsync(at(o_seen), 0, ((size_t)n_prims + 31) / 32 * 4, stream));
   LT_PREP_CHECK(hipMemsetAsync(counts, 0, (size_t)(maxLevels + 2) * kCntWords * 4, stream));
@@ -875,9 +1038,9 @@ hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint3
   const dim3 perNode((N + 255) / 256), block(256);
   hipLaunchKernelGGL(k_check_nodes, perNode, block, 0, stream, nd, N, n_prims, (uint32_t*)at(o_parent), (uint32_t*)at(o_seen), ctl);
   hipLaunchKernelGGL(k_check_prims, dim3((n_prims + 255) / 256), block, 0, stream, (const int32_t*)d_prims, n_prims, n_mats, ctl);
-  hipLaunchKernelGGL(k_subtree_ends, perNode, block, 0, stream, nd, N, (const uint32_t*)at(o_parent), (uint32_t*)at(o_end), ctl);
-  hipLaunchKernelGGL(k_leaf_ranks, perNode, block, 0, stream, nd, N, n_prims, (const uint32_t*)at(o_parent), (const uint32_t*)at(o_end),
-                     (uint32_t*)out.d_rank8, (uint32_t*)at(o_order0), ctl);
+  hipLaunchKernelGGL(k_subtree_ends, perNode, block, 0, stream, nd, N, (const uint32_t*)at(o_parent), (uint4*)at(o_up), ctl);
+  hipLaunchKernelGGL(k_leaf_ranks, perNode, block, 0, stream, nd, N, n_prims, (const uint4*)at(o_up), (uint32_t*)out.d_rank8,
+                     (uint32_t*)at(o_order0), ctl);
   LT_PREP_CHECK(hipGetLastError());
   uint32_t h_ctl[kCtlWords];
   LT_PREP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, stream));
@@ -886,19 +1049,19 @@ hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint3
   out.bvh_height = (int)h_ctl[kCtlBvhHeight];
   out.ms_check = (float)(now_ms() - t0);
   if (out.flags) {
-    (void)hipFree(scratch);
-    release(out);
+    al.put(al.self, scratch);
+    release(out, al);
     return hipSuccess;
   }
 
   // ---- the own tree
   const double t1 = now_ms();
   out.n_own = 2 * n - 1;
-  LT_PREP_CHECK(hipMalloc(&out.d_nodes2, (size_t)out.n_own * 32));
+  LT_PREP_CHECK(al.get(al.self, &out.d_nodes2, (size_t)out.n_own * 32));
   float4* own = (float4*)out.d_nodes2;
   if (!ownSplits) {
     // the caller's splits: a proper pre-order tree without unreachable nodes IS lt_retree::copy's output
-    if (out.bvh_height > maxHeight) { out.flags = kFlagNoRoom; (void)hipFree(scratch); release(out); return hipSuccess; }
+    if (out.bvh_height > maxHeight) { out.flags = kFlagNoRoom; al.put(al.self, scratch); release(out, al); return hipSuccess; }
     LT_PREP_CHECK(hipMemcpyAsync(own, d_nodes, (size_t)N * 32, hipMemcpyDeviceToDevice, stream));
     out.own_height = out.bvh_height;
   } else {
@@ -946,14 +1109,14 @@ hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint3
     out.flags |= h_ctl[kCtlFlags];
     out.own_height = (int)h_ctl[kCtlOwnHeight];
     if (out.own_height > heightLimit) out.flags |= kFlagInternal;
-    if (out.flags) { (void)hipFree(scratch); release(out); return hipSuccess; }
+    if (out.flags) { al.put(al.self, scratch); release(out, al); return hipSuccess; }
   }
   out.ms_build = (float)(now_ms() - t1);
 
   // ---- the 4-wide groups
   const double t2 = now_ms();
-  LT_PREP_CHECK(hipMalloc(&out.d_groupOf, (size_t)out.n_own * 4));
-  LT_PREP_CHECK(hipMalloc(&out.d_children, (size_t)(n - 1) * 16));
+  LT_PREP_CHECK(al.get(al.self, &out.d_groupOf, (size_t)out.n_own * 4));
+  LT_PREP_CHECK(al.get(al.self, &out.d_children, (size_t)(n - 1) * 16));
   LT_PREP_CHECK(hipMemsetAsync(out.d_groupOf, 0xff, (size_t)out.n_own * 4, stream));
   LT_PREP_CHECK(hipMemsetAsync(counts, 0, (size_t)(maxLevels + 2) * kCntWords * 4, stream));
   uint32_t* front[2] = {(uint32_t*)at(o_front0), (uint32_t*)at(o_front1)};
@@ -989,9 +1152,9 @@ hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint3
   out.groups = h_ctl[kCtlGroups];
   for (int k = 0; k < 3; k++) { out.root_lo[k] = rootBox[k]; out.root_hi[k] = rootBox[3 + k]; }
   out.ms_wide = (float)(now_ms() - t2);
-  (void)hipFree(scratch);
+  al.put(al.self, scratch);
   scratch = nullptr;
-  if (out.flags) release(out);
+  if (out.flags) release(out, al);
   return hipSuccess;
 }
 

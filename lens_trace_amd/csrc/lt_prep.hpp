@@ -27,7 +27,7 @@ struct Out {
   int wide_height = -1;         // of the 4-wide group tree, -1: none
   uint32_t n_own = 0, groups = 0;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};   // the own tree's root box
-  void* d_nodes2 = nullptr;     // hipMalloc'ed here, the caller's to free: the own tree, 32-byte nodes in pre-order
+  void* d_nodes2 = nullptr;     // from the allocator, the caller's to give back: the own tree, 32-byte nodes in pre-order
   void* d_rank8 = nullptr;      // 8 x n_prims positions of the reference's walk (lt_retree::reference_order)
   void* d_children = nullptr;   // 4 x groups binary nodes (lt_retree::collapse_wide's `children`), allocated for 4 x (leaves - 1)
   void* d_groupOf = nullptr;    // n_own
@@ -35,12 +35,19 @@ struct Out {
   int levels = 0;
 };
 
+// Where device memory comes from and goes to (lt_capi.hip keeps the buffers of the scene before for the next one of the same shape).
+struct Allocator {
+  void* self;
+  hipError_t (*get)(void* self, void** p, size_t bytes);
+  void (*put)(void* self, void* p);
+};
+
 // d_nodes / d_prims: the caller's buffers, already on the device.  ownSplits = false: the caller's splits under the own
 // structures (LT_RETREE=0).  wantWide = false: no 4-wide groups.  Returns a HIP error of a runtime call, or hipSuccess with
 // out.flags telling whether the results are to be used.  Nothing is left allocated when flags != 0 or on an error.
 hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint32_t n_prims, uint32_t n_mats, int maxHeight, int slack,
-               bool ownSplits, hipStream_t stream, Out& out);
+               bool ownSplits, hipStream_t stream, const Allocator& al, Out& out);
 
-void release(Out& out);
+void release(Out& out, const Allocator& al);
 
 }  // namespace lt_prep
