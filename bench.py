@@ -408,7 +408,7 @@ def main():
                        "frame_period_ms": round(ms_per_step, 3), "frame_latency_ms": round(frame_latency_ms, 3), "steps_in_flight": args.in_flight,
                        # which of its three (pixel-identical) walks the library timed fastest for this scene's shadow rays
                        "shadow_ray_walk": SHADOW_WALKS.get(shadow_walk, "not timed"),
-                       # the backend's own hierarchy over the caller's leaves: height, host build time at set_scene (not in any step)
+                       # the backend's own hierarchy over the caller's leaves: height, time of its preparation at set_scene (not in any step)
                        "own_hierarchy_height": own_tree[0], "own_hierarchy_build_ms": round(own_tree[1], 1)},
             "roofline": roofline("%s, %d triangles, %dx%d, %s" % (scene_name, scene.n_prims, W, H, args.program),
                                  "lt_render_kernel<%s>" % args.program if launches_per_step <= args.spp else "wavefront GI pipeline (all its stage kernels)",
@@ -439,7 +439,10 @@ def e2e_figures(args, scene, r):
       e2e_frame_ms_plugin      : RendererHIP.render() with the default scene-change contract, i.e. the caller hands over its scene
                                  with every frame as the reference's callers do (renderer_opencl.cpp:107-120): lt_hip_render_scene
                                  hashes all of it while the frame renders
-      scene_hash_ms            : that hash alone (lt_hip_set_scene of the unchanged scene), for scale: it is not added to anything"""
+      scene_hash_ms            : that hash alone (lt_hip_set_scene of the unchanged scene), for scale: it is not added to anything
+      scene_change_ms          : lt_hip_set_scene of the same scene with ANOTHER node buffer (the root's box a little larger): hash,
+                                 upload, checks, leaf order table, own hierarchy, 4-wide groups, walk records -- everything anew;
+                                 scene_prepared_on says whether kernels (lt_prep.hip) or host threads (lt_retree.hpp) made them"""
     import numpy as np
     from lens_trace_amd.renderer import RenderPropertiesHIP
     W, H = args.width, args.height
@@ -464,7 +467,18 @@ def e2e_figures(args, scene, r):
     for _ in range(steps):
         r.set_scene(scene)
     hash_ms = (time.perf_counter() - t0) / steps * 1e3
+    change = []
+    for k in range(steps + 1):
+        nodes = scene.node_view.copy()
+        nodes["boundsMax"][0][0] += 1e-3 * (k + 1)
+        other = type(scene)(nodes=nodes.view(np.uint8).reshape(-1), prims=scene.prims, materials=scene.materials, lights=scene.lights, camera=scene.camera)
+        t0 = time.perf_counter()
+        r.set_scene(other)
+        change.append((time.perf_counter() - t0) * 1e3)
+    info = r.scene_structure(3)
+    r.set_scene(scene)
     return {"e2e_frame_ms_host_buffer": round(versioned, 3), "e2e_frame_ms_plugin": round(plugin, 3), "scene_hash_ms": round(hash_ms, 3),
+            "scene_change_ms": round(min(change[1:]), 3), "scene_prepared_on": "device" if info[3] else "host",
             "e2e_readback_bytes": int(out.nbytes), "e2e_scene_bytes": int(scene.nodes.nbytes + scene.prims.nbytes + scene.materials.nbytes + scene.lights.nbytes)}
 
 

@@ -153,7 +153,7 @@ typedef struct lt_hip_stats {
   uint32_t scene_reused;        /* ... and those that found the resident scene's content unchanged (full hash) and kept it */
   int32_t own_tree_height;      /* height of the backend's own hierarchy over the scene's leaves (built at lt_hip_set_scene, walked by
                                  * every finite ray of the non-counting kernels; LT_RETREE=0 keeps the caller's splits), -1 = none: every walk uses the caller's tree */
-  float own_tree_ms;            /* host time of that build */
+  float own_tree_ms;            /* time of its preparation inside lt_hip_set_scene (device or host) */
 } lt_hip_stats;
 
 int lt_hip_abi_version(void);
@@ -189,7 +189,8 @@ int lt_hip_resolve_program(lt_hip_context* ctx, const char* kernel_file_path, in
  * (renderer_opencl.cpp:107-120), and in-place edits are honoured.
  * Derived at upload: the traversal-side triangle array (48-byte stride: A, B-A, C-A) and -- when every node's box encloses
  * its children's, which the reference's own builder guarantees -- the backend's OWN hierarchy over the caller's leaves
- * (binned surface-area heuristic, built on the host: ~0.1-0.4 s for a million triangles), the 64-byte records of its packet
+ * (binned surface-area heuristic, built by kernels -- lens_trace_amd/csrc/lt_prep.hip: ~10 ms for the whole call on a million
+ * triangles -- or, for small or unusual buffers, by host threads: lt_retree.hpp), the 64-byte records of its packet
  * walks, the 4-wide groups of quantised boxes and the leaf records of its per-lane walks and the reference's leaf order per
  * direction-sign octant.  The caller's LinearBVHNode array stays resident and is
  * what the counting kernels (LT_RENDER_FLAG_STATS / _PIXEL_COUNTERS), rays with a non-finite component and scenes whose

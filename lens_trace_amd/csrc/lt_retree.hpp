@@ -1,4 +1,5 @@
-// The backend's own traversal tree over the reference's leaves, built on the host at lt_hip_set_scene (host code only).
+// The backend's own traversal tree over the reference's leaves: the host-side build (lt_prep.hip makes the same tree with kernels
+// at lt_hip_set_scene; this one serves the scenes that path declines, small scenes, the diagnostic entry points and the tests).
 //
 // Why a different tree gives the same pixels.  The reference's traversal (acc.cl:132-217) reaches a leaf iff the ray passes the
 // slab test (acc.cl:113-130) of every ancestor's box and of the leaf's own box, and it never clips against the closest hit.

@@ -42,6 +42,7 @@ def test_single_gpu_line_has_the_contract_keys():
     cfg = d["config"]
     assert cfg["e2e_frame_ms_host_buffer"] > 0 and cfg["e2e_frame_ms_plugin"] > 0 and cfg["scene_hash_ms"] > 0
     assert cfg["frame_latency_ms"] > 0 and cfg["frame_period_ms"] == d["ms_per_step"] and cfg["steps_in_flight"] == 1
+    assert cfg["scene_change_ms"] > cfg["scene_hash_ms"] and cfg["scene_prepared_on"] in ("device", "host")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "frames" in c["sample"]
     assert d["value"] > c["value"]
