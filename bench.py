@@ -442,7 +442,8 @@ def e2e_figures(args, scene, r):
       scene_hash_ms            : that hash alone (lt_hip_set_scene of the unchanged scene), for scale: it is not added to anything
       scene_change_ms          : lt_hip_set_scene of the same scene with ANOTHER node buffer (the root's box a little larger): hash,
                                  upload, checks, leaf order table, own hierarchy, 4-wide groups, walk records -- everything anew;
-                                 scene_prepared_on says whether kernels (lt_prep.hip) or host threads (lt_retree.hpp) made them"""
+                                 scene_prepared_on says whether kernels (lt_prep.hip) or host threads (lt_retree.hpp) made them
+      e2e_frame_ms_plugin_changing_scene : RendererHIP.render() of a caller whose node buffer differs from the last call's every time"""
     import numpy as np
     from lens_trace_amd.renderer import RenderPropertiesHIP
     W, H = args.width, args.height
@@ -467,18 +468,28 @@ def e2e_figures(args, scene, r):
     for _ in range(steps):
         r.set_scene(scene)
     hash_ms = (time.perf_counter() - t0) / steps * 1e3
-    change = []
+    change, keep = [], []     # (keep: the scenes stay alive, so that no 64 MB munmap of the one before lands in the timed call)
     for k in range(steps + 1):
         nodes = scene.node_view.copy()
         nodes["boundsMax"][0][0] += 1e-3 * (k + 1)
         other = type(scene)(nodes=nodes.view(np.uint8).reshape(-1), prims=scene.prims, materials=scene.materials, lights=scene.lights, camera=scene.camera)
+        keep.append(other)
         t0 = time.perf_counter()
         r.set_scene(other)
         change.append((time.perf_counter() - t0) * 1e3)
     info = r.scene_structure(3)
+    # ... and whole frames of a caller whose node buffer is another one every call (an animation that rebuilds its tree): hash,
+    # preparation, frame, read-back
+    moving = []
+    for k in range(steps + 1):
+        props = RenderPropertiesHIP(sceneVersion=0, **dict(base, pAccelerationStructureExplicit=keep[k % len(keep)]))
+        t0 = time.perf_counter()
+        r.render(props)
+        moving.append((time.perf_counter() - t0) * 1e3)
     r.set_scene(scene)
     return {"e2e_frame_ms_host_buffer": round(versioned, 3), "e2e_frame_ms_plugin": round(plugin, 3), "scene_hash_ms": round(hash_ms, 3),
             "scene_change_ms": round(min(change[1:]), 3), "scene_prepared_on": "device" if info[3] else "host",
+            "e2e_frame_ms_plugin_changing_scene": round(sum(moving[1:]) / len(moving[1:]), 3),
             "e2e_readback_bytes": int(out.nbytes), "e2e_scene_bytes": int(scene.nodes.nbytes + scene.prims.nbytes + scene.materials.nbytes + scene.lights.nbytes)}
 
 

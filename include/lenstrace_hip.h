@@ -209,7 +209,8 @@ int lt_hip_render(lt_hip_context* ctx, const lt_hip_render_desc* desc, float* ou
 /* lt_hip_set_scene followed by lt_hip_render, as one call -- what a plugin's render() does with a caller that hands over its
  * scene every time (renderer_opencl.cpp:107-120).  Same results and same statuses as the two calls; when the four buffers have
  * the resident scene's sizes the frame is rendered while the host hashes them, and rendered again only if they turn out to have
- * changed -- so that an unchanged scene costs no hashing time on top of the frame. */
+ * changed -- so that an unchanged scene costs no hashing time on top of the frame.  After a call that found the scene changed
+ * (an animation) the next call hashes first: a millisecond in front of the frame instead of a frame rendered for nothing. */
 int lt_hip_render_scene(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims, uint64_t prim_bytes,
                         const void* materials, uint64_t material_bytes, const void* lights, uint64_t light_bytes,
                         const lt_hip_render_desc* desc, float* out_host, uint64_t out_bytes);

@@ -239,6 +239,9 @@ struct lt_hip_context {
   int bvh_height = 0;
   bool has_scene = false;
   bool device_prepared = false;      // the resident scene's derived structures were made by lt_prep.hip (not by lt_retree.hpp on the host)
+  uint64_t verdict_sizes[4] = {0, 0, 0, 0};   // sizes of the scene the shadow-walk verdicts below were timed on
+  bool verdict_sizes_valid = false;
+  bool speculate_next = true;        // lt_hip_render_scene: the last scene handed over with a frame was the resident one (render while hashing)
   SceneHash scene_hash{};                                    // content hashes (one per buffer) ...
   uint64_t scene_sizes[4] = {0, 0, 0, 0};                   // ... and sizes of the resident scene (lt_hip_set_scene)
   uint32_t scene_uploads = 0, scene_reused = 0;
@@ -686,6 +689,17 @@ extern "C" int lt_hip_set_scene(lt_hip_context* ctx, const void* nodes, uint64_t
   }
 }
 
+// The shadow-ray walk timed fastest for a scene (render_on_stream) is kept for a scene of the same shape -- the next pose of an
+// animation, an edited material: it is a matter of speed, never of pixels, and timing it again costs five frames -- and forgotten
+// when the sizes change (another scene).
+static void new_scene_walk_verdicts(lt_hip_context* ctx, const uint64_t sizes[4]) {
+  if (ctx->verdict_sizes_valid && memcmp(sizes, ctx->verdict_sizes, sizeof(ctx->verdict_sizes)) == 0 && !getenv("LT_RETIME_EVERY_SCENE")) return;
+  for (int& m : ctx->shadow_mode) m = -1;
+  ctx->shadow_modes.clear();
+  memcpy(ctx->verdict_sizes, sizes, sizeof(ctx->verdict_sizes));
+  ctx->verdict_sizes_valid = true;
+}
+
 // The device path of lt_hip_set_scene.  kDeviceDeclined: nothing of ctx was touched, the host path decides.
 constexpr int kDeviceDeclined = -1000;
 static int set_scene_on_device(lt_hip_context* ctx, const void* nodes, uint64_t node_bytes, const void* prims, uint64_t prim_bytes,
@@ -799,8 +813,7 @@ static int set_scene_on_device(lt_hip_context* ctx, const void* nodes, uint64_t 
   ctx->scene_sizes[0] = node_bytes; ctx->scene_sizes[1] = prim_bytes; ctx->scene_sizes[2] = material_bytes; ctx->scene_sizes[3] = light_bytes;
   ctx->scene_uploads++;
   ctx->device_prepared = true;
-  for (int& m : ctx->shadow_mode) m = -1;
-  ctx->shadow_modes.clear();
+  new_scene_walk_verdicts(ctx, ctx->scene_sizes);
   return LT_OK;
 }
 
@@ -868,8 +881,7 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
       LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
       ctx->scene_hash = hash;
       ctx->scene_uploads++;
-      for (int& m : ctx->shadow_mode) m = -1;   // (other lights: other shadow rays)
-      ctx->shadow_modes.clear();
+      new_scene_walk_verdicts(ctx, sizes);
       return LT_OK;
     }
   }
@@ -1013,8 +1025,7 @@ static int set_scene_impl(lt_hip_context* ctx, const void* nodes, uint64_t node_
   ctx->scene_hash = hash;
   memcpy(ctx->scene_sizes, sizes, sizeof(sizes));
   ctx->scene_uploads++;
-  for (int& m : ctx->shadow_mode) m = -1;
-  ctx->shadow_modes.clear();
+  new_scene_walk_verdicts(ctx, sizes);
   return LT_OK;
 }
 
@@ -1849,7 +1860,11 @@ extern "C" int lt_hip_render_scene(lt_hip_context* ctx, const void* nodes, uint6
     const uint64_t sizes[4] = {node_bytes, prim_bytes, material_bytes, light_bytes};
     const void* const bufs[4] = {nodes, prims, materials, lights};
     const bool continues = desc && desc->frame_count && desc->accumulate && desc->accumulate_base > 0;   // (reads the caller's buffer: no second try)
-    const bool speculate = ctx->has_scene && memcmp(sizes, ctx->scene_sizes, sizeof(sizes)) == 0 && !getenv("LT_SCENE_ALWAYS_UPLOAD") && !continues;
+    // Rendering from the resident copy while the host hashes what came with the frame pays when the scene is the resident one --
+    // a still scene, every call but the first.  A caller whose scene changed last time (an animation) gets the hash first: a
+    // millisecond in front of the frame instead of a whole frame rendered for nothing.
+    const bool speculate = ctx->has_scene && ctx->speculate_next && memcmp(sizes, ctx->scene_sizes, sizeof(sizes)) == 0 &&
+                           !getenv("LT_SCENE_ALWAYS_UPLOAD") && !continues;
     uint64_t need = 0;
     bool staged = false;
     int rc;
@@ -1868,9 +1883,12 @@ extern "C" int lt_hip_render_scene(lt_hip_context* ctx, const void* nodes, uint6
       }
       rc = finish_pending(ctx);
       if (rc) return rc;
+      ctx->speculate_next = false;
       rc = set_scene_impl(ctx, nodes, node_bytes, prims, prim_bytes, materials, material_bytes, lights, light_bytes, &hash);
     } else {
+      const uint32_t reused = ctx->scene_reused;
       rc = set_scene_impl(ctx, nodes, node_bytes, prims, prim_bytes, materials, material_bytes, lights, light_bytes, nullptr);
+      ctx->speculate_next = rc == LT_OK && ctx->scene_reused != reused;   // (the resident scene again: the next frame may start at once)
     }
     if (rc) return rc;
     rc = lt_hip_render(ctx, desc, out_host, out_bytes);

@@ -56,6 +56,10 @@ __device__ __forceinline__ uint32_t wave_sum_u(uint32_t v) {
   for (int m = 32; m; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m);
   return v;
 }
+// a maximum many wavefronts report: one address serves an atomic every ~12 ns, so only a value above what stands there is sent
+__device__ __forceinline__ void raise_max(uint32_t* p, uint32_t v) {
+  if (__atomic_load_n(p, __ATOMIC_RELAXED) < v) atomicMax(p, v);
+}
 __device__ __forceinline__ float half_area(const float* lo, const float* hi) {
   const float dx = __fsub_rn(hi[0], lo[0]), dy = __fsub_rn(hi[1], lo[1]), dz = __fsub_rn(hi[2], lo[2]);
   return __fadd_rn(__fadd_rn(__fmul_rn(dx, dy), __fmul_rn(dy, dz)), __fmul_rn(dz, dx));
@@ -189,7 +193,7 @@ __global__ void k_leaf_ranks(const float4* __restrict__ nd, uint32_t n, uint32_t
     }
   }
   const uint32_t deepest = wave_max_u(f ? 0u : depth);
-  if (lane_id() == 0 && deepest) atomicMax(&ctl[kCtlBvhHeight], deepest);
+  if (lane_id() == 0 && deepest) raise_max(&ctl[kCtlBvhHeight], deepest);
   if (f) atomicOr(&ctl[kCtlFlags], f);
 }
 
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(256) void k_tiny(const float4* __restrict__ nd, con
     if (sp > 64) { bad = 1; break; }
   }
   if (lane == 0) {
-    atomicMax(&ctl[kCtlOwnHeight], deepest);
+    raise_max(&ctl[kCtlOwnHeight], deepest);
     if (bad) atomicOr(&ctl[kCtlFlags], (uint32_t)kFlagInternal);
   }
 }
@@ -474,16 +478,46 @@ __device__ __forceinline__ void leaf_of(const LEAVES& cl, int j, Leaf& l) {
 }
 
 // ------------------------------------------------------------------------------------------ one wavefront per range, looping
-__global__ __launch_bounds__(256) void k_mid(const float4* __restrict__ nd, const uint32_t* __restrict__ orderIn, uint32_t* __restrict__ orderOut,
+constexpr int kMidBlock = 512;
+__device__ void k_mid_range(const float4* __restrict__ nd, const uint32_t* __restrict__ orderIn, uint32_t* __restrict__ orderOut, const Range rg,
+                            uint32_t* bins, float4* __restrict__ out, int heightLimit, uint32_t* __restrict__ ctl, Range* child);
+__global__ __launch_bounds__(kMidBlock) void k_mid(const float4* __restrict__ nd, const uint32_t* __restrict__ orderIn, uint32_t* __restrict__ orderOut,
                                               const Range* __restrict__ list, const uint32_t* __restrict__ counts, float4* __restrict__ out,
                                               int heightLimit, Range* __restrict__ nextBig, Range* __restrict__ nextMid, Range* __restrict__ nextTiny,
                                               uint32_t* __restrict__ nextCounts, uint32_t* __restrict__ ctl) {
-  __shared__ uint32_t s_bins[4][kRangeBins];
-  const uint32_t wave = threadIdx.x >> 6, lane = lane_id(), w = blockIdx.x * 4 + wave;
-  if (w >= counts[kCntMid]) return;
-  const Range rg = list[w];
+  __shared__ uint32_t s_bins[kMidBlock / 64][kRangeBins];
+  __shared__ uint32_t s_req[3], s_base[3];
+  const uint32_t wave = threadIdx.x >> 6, lane = lane_id(), w = blockIdx.x * (kMidBlock / 64) + wave;
+  if (threadIdx.x < 3) s_req[threadIdx.x] = 0u;
+  __syncthreads();
+  // the children of this wavefront's range: their lists' slots are claimed per WORKGROUP (one atomic per list instead of two per range)
+  Range child[2] = {Range{0u, 0u, 0u, 0u}, Range{0u, 0u, 0u, 0u}};
+  int kind[2] = {-1, -1};
+  uint32_t slot[2] = {0u, 0u};
+  if (w < counts[kCntMid]) k_mid_range(nd, orderIn, orderOut, list[w], s_bins[wave], out, heightLimit, ctl, child);
+  if (lane == 0)
+    for (int q = 0; q < 2; q++) {
+      const uint32_t count = child[q].end - child[q].start;
+      if (count < 2) continue;
+      kind[q] = count <= kTiny ? kCntTiny : (count <= kChunk ? kCntMid : kCntBig);
+      slot[q] = atomicAdd(&s_req[kind[q]], 1u);
+    }
+  __syncthreads();
+  if (threadIdx.x < 3 && s_req[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&nextCounts[threadIdx.x], s_req[threadIdx.x]);
+  __syncthreads();
+  if (lane == 0)
+    for (int q = 0; q < 2; q++) {
+      if (kind[q] < 0) continue;
+      Range* to = kind[q] == kCntTiny ? nextTiny : (kind[q] == kCntMid ? nextMid : nextBig);
+      to[s_base[kind[q]] + slot[q]] = child[q];
+    }
+}
+
+// one range of k_mid (all 64 lanes); child[]: the two ranges it leaves behind (lane 0's copy counts)
+__device__ void k_mid_range(const float4* __restrict__ nd, const uint32_t* __restrict__ orderIn, uint32_t* __restrict__ orderOut, const Range rg,
+                            uint32_t* bins, float4* __restrict__ out, int heightLimit, uint32_t* __restrict__ ctl, Range* child) {
+  const uint32_t lane = lane_id();
   const uint32_t cnt = rg.end - rg.start;
-  uint32_t* bins = s_bins[wave];
   // bounds
   uint32_t olo[3] = {kMinIdentity, kMinIdentity, kMinIdentity}, ohi[3] = {kMaxIdentity, kMaxIdentity, kMaxIdentity};
   uint32_t ocmin[3] = {kMinIdentity, kMinIdentity, kMinIdentity}, ocmax[3] = {kMaxIdentity, kMaxIdentity, kMaxIdentity};
@@ -617,9 +651,9 @@ __global__ __launch_bounds__(256) void k_mid(const float4* __restrict__ nd, cons
   if (lane == 0) {
     if (doneL != left) atomicOr(&ctl[kCtlFlags], (uint32_t)kFlagInternal);
     store_interior(out, rg.node, lo, hi, rightNode, dim);
-    emit_child(Range{rg.start, rg.start + left, rg.node + 1, rg.depth + 1}, nextBig, nextMid, nextTiny, nextCounts);
-    emit_child(Range{rg.start + left, rg.end, rightNode, rg.depth + 1}, nextBig, nextMid, nextTiny, nextCounts);
-    atomicMax(&ctl[kCtlOwnHeight], rg.depth + 1);   // (both children exist one level down)
+    child[0] = Range{rg.start, rg.start + left, rg.node + 1, rg.depth + 1};
+    child[1] = Range{rg.start + left, rg.end, rightNode, rg.depth + 1};
+    raise_max(&ctl[kCtlOwnHeight], rg.depth + 1);   // (both children exist one level down)
   }
 }
 
@@ -805,7 +839,7 @@ __global__ __launch_bounds__(256) void k_big_split(const float4* __restrict__ nd
       store_interior(out, c.rg.node, b.lo, b.hi, rightNode, sp.dim);
       emit_child(Range{c.rg.start, c.rg.start + sp.left, c.rg.node + 1, c.rg.depth + 1}, nextBig, nextMid, nextTiny, nextCounts);
       emit_child(Range{c.rg.start + sp.left, c.rg.end, rightNode, c.rg.depth + 1}, nextBig, nextMid, nextTiny, nextCounts);
-      atomicMax(&ctl[kCtlOwnHeight], c.rg.depth + 1);
+      raise_max(&ctl[kCtlOwnHeight], c.rg.depth + 1);
     }
   }
 }
@@ -1094,7 +1128,7 @@ hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint3
                            (const uint32_t*)at(o_chunkRange), (const SplitRec*)at(o_splits), (const uint32_t*)at(o_chunkLeft), own, ctl);
       }
       if (nm + nb)
-        hipLaunchKernelGGL(k_mid, dim3((nm + nb + 3) / 4), block, 0, stream, nd, order[cur], order[nxt], mid[cur], curCounts, own, heightLimit,
+        hipLaunchKernelGGL(k_mid, dim3((nm + nb + kMidBlock / 64 - 1) / (kMidBlock / 64)), dim3(kMidBlock), 0, stream, nd, order[cur], order[nxt], mid[cur], curCounts, own, heightLimit,
                            big[nxt], mid[nxt], tiny[nxt], nextCounts, ctl);
       if (nt)
         hipLaunchKernelGGL(k_tiny, dim3((nt + 3) / 4), block, 0, stream, nd, order[cur], tiny[cur], curCounts, own, heightLimit, ctl);

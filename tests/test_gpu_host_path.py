@@ -114,3 +114,28 @@ def test_edits_that_leave_the_nodes_alone_keep_the_hierarchies(monkeypatch):
         out, st = frame()
         assert np.array_equal(out, po.render(s, cam, W, H, po.ACCUMULATOR))
     r.close()
+
+
+def test_a_scene_that_changes_with_every_frame_is_hashed_before_the_frame():
+    """An animation: after a call that found the scene changed, the next call looks at the scene first (no frame rendered on the
+    old one for nothing); after a call that found it unchanged, frames start at once again.  Either way the pixels are the
+    scene's that came with the frame."""
+    a = sc.load_ltsb(os.path.join(GOLDEN, "cornell_box_O0.ltsb")).validate()
+    b = sc.load_ltsb(os.path.join(GOLDEN, "cornell_box_O0.ltsb")).validate()
+    mb = b.materials.view(sc.MATERIAL_DTYPE)
+    mb["diffuse"][:] = mb["diffuse"][:, ::-1].copy()
+    cam = sc.camera_bytes(0.0, 2.5, -50.0, 0.0, 0.0, 0.0, 2)
+    W, H = 160, 120
+    want = {id(a): po.render(a, cam, W, H, po.ACCUMULATOR), id(b): po.render(b, cam, W, H, po.ACCUMULATOR)}
+    assert not np.array_equal(want[id(a)], want[id(b)])
+    r = RendererHIP(0)
+    uploads = 0
+    last = None
+    for s in (a, b, a, b, b, b, a, a, b):
+        out = np.full((H, W, 3), np.nan, dtype=np.float32)
+        r.render(Props(ACC, (W, H, 3), out, s, pCamera=cam))
+        uploads += 0 if s is last else 1
+        last = s
+        st = r.stats()
+        assert np.array_equal(out, want[id(s)]) and st["scene_uploads"] == uploads
+    r.close()

@@ -21,7 +21,7 @@ for line in open(sys.argv[1]):
             rows.append((cur["codeLenInByte"], cur.get("NumVgprs", 0), cur.get("TotalNumSgprs", 0), cur.get("ScratchSize", 0), cur["Occupancy"], name))
             name = None
 names = subprocess.run(["c++filt"], input="\n".join(r[5] for r in rows), capture_output=True, text=True).stdout.splitlines()
-print("# machine-code size of every kernel of liblenstrace-hip.so (tools/isa_size.py on the gfx950 assembly of lt_capi.hip), largest first:")
+print("# machine-code size of every kernel of liblenstrace-hip.so (tools/isa_size.py on the gfx950 assembly of lt_capi.hip and lt_prep.hip), largest first:")
 print("# bytes, VGPRs, SGPRs, scratch bytes per lane, waves per SIMD.  The instruction cache two CUs share holds 64 KB; the")
 print("# instruction-cache hit rate of the bench launch is in issue_profile.json (0.999997): the walks' loops are small and hot.")
 for (size, vg, sg, scratch, occ, _), n in sorted(zip(rows, names), key=lambda t: -t[0][0]):
