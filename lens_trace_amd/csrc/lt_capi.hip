@@ -734,18 +734,38 @@ static int set_scene_on_device(lt_hip_context* ctx, const void* nodes, uint64_t 
   Guard guard{ctx->pool, al, &d_nodes, &d_prims, &prep};
   LT_HIP_CHECK(ctx, ctx->pool.get(&d_nodes, node_bytes));
   LT_HIP_CHECK(ctx, ctx->pool.get(&d_prims, prim_bytes));
-  LT_HIP_CHECK(ctx, hipMemcpyAsync(d_nodes, nodes, node_bytes, hipMemcpyHostToDevice, ctx->stream));
-  LT_HIP_CHECK(ctx, hipMemcpyAsync(d_prims, prims, prim_bytes, hipMemcpyHostToDevice, ctx->stream));
-  lap("upload nodes, primitives");
+  LT_HIP_CHECK(ctx, hipMemcpy(d_nodes, nodes, node_bytes, hipMemcpyHostToDevice));
+  lap("upload nodes");
+  // The hierarchy is built from the nodes alone: the primitives (the larger buffer) travel meanwhile, sent by a thread of their
+  // own (a copy from pageable memory keeps its caller until it is done) -- or, if that thread cannot be had, right here.
+  std::thread primThread;
+  hipError_t primError = hipSuccess;
+  bool primSent = false;
+  try {
+    primThread = std::thread([&]() {
+      primError = hipSetDevice(ctx->device);
+      if (primError == hipSuccess) primError = hipMemcpy(d_prims, prims, prim_bytes, hipMemcpyHostToDevice);
+    });
+    primSent = true;
+  } catch (...) {
+  }
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{primThread};   // (every exit below waits for it)
+  if (!primSent) LT_HIP_CHECK(ctx, hipMemcpy(d_prims, prims, prim_bytes, hipMemcpyHostToDevice));
   const char* re = getenv("LT_RETREE");
   const char* sl = getenv("LT_RETREE_SLACK");
   const auto t0 = std::chrono::steady_clock::now();
   // (height <= 30: the packet walks' stack, one VGPR, holds 2 * height + 2 entries at most; LT_RETREE=0: the caller's splits)
-  LT_HIP_CHECK(ctx, lt_prep::run(d_nodes, n_nodes, d_prims, n_prims, n_mats, 30, sl ? atoi(sl) : 2, !(re && atoi(re) == 0), ctx->stream, al, prep));
+  LT_HIP_CHECK(ctx, lt_prep::run(d_nodes, n_nodes, nullptr, n_prims, n_mats, 30, sl ? atoi(sl) : 2, !(re && atoi(re) == 0), ctx->stream, al, prep));
   if (timing) fprintf(stderr, "[lt set_scene] device: checks + leaf order %.2f ms, own hierarchy %.2f ms (%d levels), 4-wide groups %.2f ms, flags %u\n",
                       prep.ms_check, prep.ms_build, prep.levels, prep.ms_wide, prep.flags);
   if (prep.flags != 0 || prep.bvh_height > kMaxStack) return kDeviceDeclined;
   lap("device preparation");
+  if (primThread.joinable()) primThread.join();
+  LT_HIP_CHECK(ctx, primError);
+  bool primsOk = false;
+  LT_HIP_CHECK(ctx, lt_prep::check_primitives(d_prims, n_prims, n_mats, ctx->stream, (uint32_t*)ctx->d_stats, primsOk));
+  if (!primsOk) return kDeviceDeclined;
+  lap("primitives arrived, checked");
   // from here on the scene is good: it replaces the resident one
   LT_HIP_CHECK(ctx, hipDeviceSynchronize());
   free_scene(ctx);

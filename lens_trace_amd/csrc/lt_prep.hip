@@ -1011,6 +1011,18 @@ struct Carver {
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 
+hipError_t check_primitives(const void* d_prims, uint32_t n_prims, uint32_t n_mats, hipStream_t stream, uint32_t* d_word, bool& ok) {
+  hipError_t e = hipMemsetAsync(d_word, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_check_prims, dim3((n_prims + 255) / 256), dim3(256), 0, stream, (const int32_t*)d_prims, n_prims, n_mats, d_word);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  uint32_t flags = 0;
+  if ((e = hipMemcpyAsync(&flags, d_word, sizeof(flags), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  ok = flags == 0;
+  return hipSuccess;
+}
+
 void release(Out& out, const Allocator& al) {
   for (void** p : {&out.d_nodes2, &out.d_rank8, &out.d_children, &out.d_groupOf}) {
     if (*p) al.put(al.self, *p);
@@ -1071,7 +1083,7 @@ hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint3
   LT_PREP_CHECK(hipMemsetAsync(at(o_order0), 0xff, (size_t)n * 4, stream));
   const dim3 perNode((N + 255) / 256), block(256);
   hipLaunchKernelGGL(k_check_nodes, perNode, block, 0, stream, nd, N, n_prims, (uint32_t*)at(o_parent), (uint32_t*)at(o_seen), ctl);
-  hipLaunchKernelGGL(k_check_prims, dim3((n_prims + 255) / 256), block, 0, stream, (const int32_t*)d_prims, n_prims, n_mats, ctl);
+  if (d_prims) hipLaunchKernelGGL(k_check_prims, dim3((n_prims + 255) / 256), block, 0, stream, (const int32_t*)d_prims, n_prims, n_mats, ctl);
   hipLaunchKernelGGL(k_subtree_ends, perNode, block, 0, stream, nd, N, (const uint32_t*)at(o_parent), (uint4*)at(o_up), ctl);
   hipLaunchKernelGGL(k_leaf_ranks, perNode, block, 0, stream, nd, N, n_prims, (const uint4*)at(o_up), (uint32_t*)out.d_rank8,
                      (uint32_t*)at(o_order0), ctl);

@@ -42,12 +42,16 @@ struct Allocator {
   void (*put)(void* self, void* p);
 };
 
-// d_nodes / d_prims: the caller's buffers, already on the device.  ownSplits = false: the caller's splits under the own
+// d_nodes / d_prims: the caller's buffers, already on the device (d_prims may be null: see check_primitives).  ownSplits = false: the caller's splits under the own
 // structures (LT_RETREE=0).  wantWide = false: no 4-wide groups.  Returns a HIP error of a runtime call, or hipSuccess with
 // out.flags telling whether the results are to be used.  Nothing is left allocated when flags != 0 or on an error.
 hipError_t run(const void* d_nodes, uint32_t n_nodes, const void* d_prims, uint32_t n_prims, uint32_t n_mats, int maxHeight, int slack,
                bool ownSplits, hipStream_t stream, const Allocator& al, Out& out);
 
 void release(Out& out, const Allocator& al);
+
+// materialIndex of every primitive in range?  (d_prims == nullptr in run(): the caller checks them with this, e.g. because its
+// primitives were still on their way while the hierarchy was built from the nodes.)
+hipError_t check_primitives(const void* d_prims, uint32_t n_prims, uint32_t n_mats, hipStream_t stream, uint32_t* d_word, bool& ok);
 
 }  // namespace lt_prep
