@@ -246,12 +246,27 @@ __device__ inline float distance4(V4 a, V4 b) {
   return Math<DEVLIBM>::sqrt_in_distance(l2);
 }
 
+// fmod(x, M_PI), bit for bit.  fmod is exact -- the result IS x - n y for n = trunc(x / y), a double -- so any way of finding n
+// gives the library's bits: n from one multiplication by 1 / pi (within one of the truth while n < 2^40), the remainder from ONE
+// fused multiply-add (no rounding: the exact value is a double), a second one when n was off by one (the sign, resp. r >= y,
+// of the rounded remainder tells: rounding never crosses 0 or the double y).  The library's fmod is a long-division loop.
+// (tests/test_gpu_parity.py holds it against fmod() over the arguments random() makes and over edge cases.)
+__device__ __forceinline__ double fmod_pi(double x) {
+  const double ax = __builtin_fabs(x);
+  if (!(ax < 0x1p+40)) return fmod(x, M_PI);   // (huge, infinite or NaN: the library's own)
+  double n = __builtin_floor(ax * 0.31830988618379067);
+  double r = __builtin_fma(-n, M_PI, ax);
+  if (r < 0.0) r = __builtin_fma(-(n - 1.0), M_PI, ax);
+  else if (r >= M_PI) r = __builtin_fma(-(n + 1.0), M_PI, ax);
+  return __builtin_copysign(r, x);
+}
+
 // acc.cl:63-66: float dot, then double add / fmod / sin / mul, then float fract
 template <int M = 0>
 __device__ inline float random_(float uvx, float uvy, float seed) {
   float d = dot2(uvx, uvy, 12.9898f, 78.233f);
   double x = Math<M>::kShipped ? __builtin_fma(1113.1, (double)seed, (double)d) : (double)d + 1113.1 * (double)seed;
-  float a = (float)(sin(fmod(x, M_PI)) * 43758.5453);
+  float a = (float)(sin(fmod_pi(x)) * 43758.5453);
   return a - __builtin_floorf(a);
 }
 
@@ -653,17 +668,21 @@ __device__ __forceinline__ bool own_walk_step(const SceneDev& sc, const Ray& ray
   const uint4* rec = (const uint4*)((const char*)sc.wide + ((size_t)(e & 0x7fffffffu) << 6));
   const uint4 s0 = rec[0], s1 = rec[1], s2 = rec[2], s3 = rec[3];
   if ((int)e < 0) {   // a leaf: A e1.x | e1.yz e2.xy | e2.z lo | hi prim
-    if (box_test_finite(__uint_as_float(s2.y), __uint_as_float(s2.z), __uint_as_float(s2.w), __uint_as_float(s3.x), __uint_as_float(s3.y),
+    // The triangle first, the reference's test of the leaf's own box for the lanes that hit it: the box is what the group's
+    // conservative test has just let this lane through, so it hardly ever fails, while most triangles are missed -- and a test
+    // that some lane of the wavefront needs is paid for by all of them.  (Accepted = both, in either order.)
+    const int prim = (int)s3.w;
+    const float4 t0 = make_float4(__uint_as_float(s0.x), __uint_as_float(s0.y), __uint_as_float(s0.z), __uint_as_float(s0.w));
+    const float4 t1 = make_float4(__uint_as_float(s1.x), __uint_as_float(s1.y), __uint_as_float(s1.z), __uint_as_float(s1.w));
+    Hit trial = pl;
+    if (intersect_triangle_data<PROGRAM>(t0, t1, make_float4(__uint_as_float(s2.x), 0.0f, 0.0f, 0.0f), ray, trial, sc.fastRcp != 0u,
+                                         ANYHIT ? nullptr : sc.rank8, w.octant, prim) &&
+        box_test_finite(__uint_as_float(s2.y), __uint_as_float(s2.z), __uint_as_float(s2.w), __uint_as_float(s3.x), __uint_as_float(s3.y),
                         __uint_as_float(s3.z), ray, ix, iy, iz)) {
-      const int prim = (int)s3.w;
-      const float4 t0 = make_float4(__uint_as_float(s0.x), __uint_as_float(s0.y), __uint_as_float(s0.z), __uint_as_float(s0.w));
-      const float4 t1 = make_float4(__uint_as_float(s1.x), __uint_as_float(s1.y), __uint_as_float(s1.z), __uint_as_float(s1.w));
-      if (intersect_triangle_data<PROGRAM>(t0, t1, make_float4(__uint_as_float(s2.x), 0.0f, 0.0f, 0.0f), ray, pl, sc.fastRcp != 0u,
-                                           ANYHIT ? nullptr : sc.rank8, w.octant, prim)) {
-        pl.prim = prim;
-        pl.hitType = 1;
-        if (ANYHIT) return true;
-      }
+      pl = trial;
+      pl.prim = prim;
+      pl.hitType = 1;
+      if (ANYHIT) return true;
     }
   } else {
     // the links of the slots entered go on the stack (leaves sit in a group's last slots: they come off first).  (Keeping the last

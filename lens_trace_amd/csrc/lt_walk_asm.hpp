@@ -124,6 +124,50 @@ typedef unsigned long long lt_u64;
   "v_max_f32_e32 %[t0], 1, %[t0]\n"                   \
   "v_cmpx_ge_f32_e64 " LT_R_HML ", %[t1], %[t0]\n"
 
+// ... the same test AFTER the triangle test (LT_ASM_WALK: a leaf's box is what the parent's conservative test has just let some
+// lane through, so it hardly ever stops the whole wavefront, while most triangles are missed by every lane: the box test then
+// only has to run for the lanes that hit the triangle, i.e. seldom).  t0 .. t3 hold invDet, u, v, t by then.
+#define LT_ASM_BOXX_LATE(NX, NY, NZ, FX, FY, FZ)       \
+  "v_sub_f32_e32 %[t4], " NX ", %[ox]\n"              \
+  "v_sub_f32_e32 %[t5], " NY ", %[oy]\n"              \
+  "v_sub_f32_e32 %[t6], " NZ ", %[oz]\n"              \
+  "v_mul_f32_e32 %[t4], %[t4], %[ix]\n"               \
+  "v_mul_f32_e32 %[t5], %[t5], %[iy]\n"               \
+  "v_mul_f32_e32 %[t6], %[t6], %[iz]\n"               \
+  "v_max3_f32 %[t4], %[t4], %[t5], %[t6]\n"           \
+  "v_sub_f32_e32 %[t5], " FX ", %[ox]\n"              \
+  "v_sub_f32_e32 %[t6], " FY ", %[oy]\n"              \
+  "v_sub_f32_e32 %[t7], " FZ ", %[oz]\n"              \
+  "v_mul_f32_e32 %[t5], %[t5], %[ix]\n"               \
+  "v_mul_f32_e32 %[t6], %[t6], %[iy]\n"               \
+  "v_mul_f32_e32 %[t7], %[t7], %[iz]\n"               \
+  "v_min3_f32 %[t5], %[t5], %[t6], %[t7]\n"           \
+  "v_max_f32_e32 %[t4], 1, %[t4]\n"                   \
+  "v_cmpx_ge_f32_e64 " LT_R_HML ", %[t5], %[t4]\n"
+#define LT_ASM_BOXX_G_LATE(LX, LY, LZ, HX, HY, HZ)     \
+  "v_sub_f32_e32 %[t4], " LX ", %[ox]\n"              \
+  "v_sub_f32_e32 %[t5], " HX ", %[ox]\n"              \
+  "v_mul_f32_e32 %[t4], %[t4], %[ix]\n"               \
+  "v_mul_f32_e32 %[t5], %[t5], %[ix]\n"               \
+  "v_min_f32_e32 %[t6], %[t4], %[t5]\n"               \
+  "v_max_f32_e32 %[t7], %[t4], %[t5]\n"               \
+  "v_sub_f32_e32 %[t4], " LY ", %[oy]\n"              \
+  "v_sub_f32_e32 %[t5], " HY ", %[oy]\n"              \
+  "v_mul_f32_e32 %[t4], %[t4], %[iy]\n"               \
+  "v_mul_f32_e32 %[t5], %[t5], %[iy]\n"               \
+  "v_min_f32_e32 %[t8], %[t4], %[t5]\n"               \
+  "v_max_f32_e32 %[t9], %[t4], %[t5]\n"               \
+  "v_sub_f32_e32 %[t4], " LZ ", %[oz]\n"              \
+  "v_sub_f32_e32 %[t5], " HZ ", %[oz]\n"              \
+  "v_mul_f32_e32 %[t4], %[t4], %[iz]\n"               \
+  "v_mul_f32_e32 %[t5], %[t5], %[iz]\n"               \
+  "v_min_f32_e32 %[t10], %[t4], %[t5]\n"              \
+  "v_max_f32_e32 %[t0], %[t4], %[t5]\n"               \
+  "v_max3_f32 %[t6], %[t6], %[t8], %[t10]\n"          \
+  "v_min3_f32 %[t7], %[t7], %[t9], %[t0]\n"           \
+  "v_max_f32_e32 %[t6], 1, %[t6]\n"                   \
+  "v_cmpx_ge_f32_e64 " LT_R_HML ", %[t7], %[t6]\n"
+
 // Box register triples: record 0 left s36-38 / s39-41, right s44-46 / s47-49; record 1 left s52-54 / s55-57, right s60-62 /
 // s63-65; leaf box s45-47 / s48-50.
 #define LT_LOHI_0 "s36", "s37", "s38", "s39", "s40", "s41"
@@ -179,24 +223,34 @@ typedef unsigned long long lt_u64;
 // plane of axis a is the box's max when direction component a is negative (bit a of NEG).
 #define LT_BC_LT_NF_0(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(LX, LY, LZ, HX, HY, HZ, OUT)
 #define LT_BX_LT_NF_0(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(LX, LY, LZ, HX, HY, HZ)
+#define LT_BXL_LT_NF_0(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX_LATE(LX, LY, LZ, HX, HY, HZ)
 #define LT_BC_LT_NF_1(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(HX, LY, LZ, LX, HY, HZ, OUT)
 #define LT_BX_LT_NF_1(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(HX, LY, LZ, LX, HY, HZ)
+#define LT_BXL_LT_NF_1(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX_LATE(HX, LY, LZ, LX, HY, HZ)
 #define LT_BC_LT_NF_2(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(LX, HY, LZ, HX, LY, HZ, OUT)
 #define LT_BX_LT_NF_2(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(LX, HY, LZ, HX, LY, HZ)
+#define LT_BXL_LT_NF_2(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX_LATE(LX, HY, LZ, HX, LY, HZ)
 #define LT_BC_LT_NF_3(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(HX, HY, LZ, LX, LY, HZ, OUT)
 #define LT_BX_LT_NF_3(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(HX, HY, LZ, LX, LY, HZ)
+#define LT_BXL_LT_NF_3(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX_LATE(HX, HY, LZ, LX, LY, HZ)
 #define LT_BC_LT_NF_4(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(LX, LY, HZ, HX, HY, LZ, OUT)
 #define LT_BX_LT_NF_4(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(LX, LY, HZ, HX, HY, LZ)
+#define LT_BXL_LT_NF_4(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX_LATE(LX, LY, HZ, HX, HY, LZ)
 #define LT_BC_LT_NF_5(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(HX, LY, HZ, LX, HY, LZ, OUT)
 #define LT_BX_LT_NF_5(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(HX, LY, HZ, LX, HY, LZ)
+#define LT_BXL_LT_NF_5(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX_LATE(HX, LY, HZ, LX, HY, LZ)
 #define LT_BC_LT_NF_6(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(LX, HY, HZ, HX, LY, LZ, OUT)
 #define LT_BX_LT_NF_6(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(LX, HY, HZ, HX, LY, LZ)
+#define LT_BXL_LT_NF_6(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX_LATE(LX, HY, HZ, HX, LY, LZ)
 #define LT_BC_LT_NF_7(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC(HX, HY, HZ, LX, LY, LZ, OUT)
 #define LT_BX_LT_NF_7(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX(HX, HY, HZ, LX, LY, LZ)
+#define LT_BXL_LT_NF_7(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX_LATE(HX, HY, HZ, LX, LY, LZ)
 #define LT_BC_LT_NF_G(LX, LY, LZ, HX, HY, HZ, OUT) LT_ASM_BOXC_G(LX, LY, LZ, HX, HY, HZ, OUT)
 #define LT_BX_LT_NF_G(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX_G(LX, LY, LZ, HX, HY, HZ)
+#define LT_BXL_LT_NF_G(LX, LY, LZ, HX, HY, HZ) LT_ASM_BOXX_G_LATE(LX, LY, LZ, HX, HY, HZ)
 #define LT_BC(NF, LOHI, OUT) LT_BC_##NF(LOHI, OUT)
 #define LT_BX(NF, LOHI) LT_BX_##NF(LOHI)
+#define LT_BXL(NF, LOHI) LT_BXL_##NF(LOHI)
 
 // branch-free push of a child reference: written at the top, kept iff some lane hit the child
 #define LT_ASM_PUSH(REF, HM)                        \
@@ -372,11 +426,11 @@ typedef unsigned long long lt_u64;
   "s_load_dwordx16 " LT_R_REC0 ", %[pairs], " LT_R_TMPLO "\n"                                                                   \
   "s_mov_b64 exec, " LIVE "\n"                                                                                                  \
   "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
-  LT_BX(NF, LT_LOHI_LEAF)                           /* the reference's own test of the leaf's own box */                        \
   IGNORE                                                                                                                        \
-  "s_cbranch_execz .LleafEnd%=\n"                                                                                               \
   LT_ASM_TRI_PART1                                                                                                              \
   LT_ASM_TRI_PART2                                                                                                              \
+  "s_cbranch_execz .LleafEnd%=\n"                                                                                               \
+  LT_BXL(NF, LT_LOHI_LEAF)                          /* the reference's own test of the leaf's own box, for the lanes that hit the triangle */ \
   ACCEPT                                                                                                                        \
   ".LleafEnd%=:\n"                                                                                                              \
   "s_branch .Lpop%=\n"                                                                                                          \

@@ -71,3 +71,19 @@ def test_user_program_compile_errors_are_reported(renderer):
     assert "this_function_does_not_exist" in str(e.value)
     with pytest.raises(C.LensTraceError):
         renderer.render(RenderPropertiesHIP(os.path.join(HERE, "missing.hip"), (8, 8, 3), out, s, pCamera=CAM))
+
+
+def test_fmod_by_pi_in_closed_form_is_the_librarys_fmod(renderer):
+    """random() (acc.cl:63-66) takes fmod(x, pi) in double precision; the kernels compute it as x - n pi with n from one
+    multiplication and the remainder from a fused multiply-add (lt_device.hpp: fmod_pi -- fmod is exact, so any way of finding n
+    gives the library's bits).  A probe program compares the two, bit for bit, on the arguments random() makes for every pixel of
+    a 4K-sized film grid and 480 seeds, their negatives and rescalings, and edge values (multiples of pi, the neighbours of the
+    double pi, denormals, 2^40 where the library's own takes over, infinities, NaN)."""
+    s = sc.load_ltsb(os.path.join(GOLDEN, "cornell_box_O0.ltsb")).validate()
+    W, H = 480, 270
+    for frame in range(5):
+        out = np.empty((H, W, 3), dtype=np.float32)
+        cam = sc.camera_bytes(0.0, 2.5, -50.0, 0.0, 0.0, 0.0, frame)
+        renderer.render(RenderPropertiesHIP(os.path.join(HERE, "fmod_check.hip"), (W, H, 3), out, s, pCamera=cam, portableMath=False))
+        assert out[..., 1].min() == out[..., 1].max() == 96 * 5 + 2 * 25
+        assert out[..., 0].max() == 0.0, "%d pixels saw a difference" % int((out[..., 0] != 0).sum())
