@@ -169,3 +169,34 @@ def test_frames_do_not_depend_on_who_prepared_the_scene(monkeypatch):
         assert r.scene_structure(3)[3] == int(device)
         r.close()
     assert np.array_equal(frames[0], frames[2]) and np.array_equal(frames[1], frames[3])
+
+
+def chain_scene(n, seed=3):
+    """The caller's tree as a right-deep chain (interior k: left = leaf k, right = the rest): height n - 1, proper pre-order."""
+    base = random_triangles(seed, n)
+    pv = base.prim_view
+    lo = np.minimum(np.minimum(pv["positionA"], pv["positionB"]), pv["positionC"])
+    hi = np.maximum(np.maximum(pv["positionA"], pv["positionB"]), pv["positionC"])
+    nodes = np.zeros(2 * n - 1, dtype=sc.NODE_DTYPE)
+    for k in range(n - 1):
+        i = 2 * k
+        nodes[i]["boundsMin"], nodes[i]["boundsMax"] = lo[k:].min(axis=0), hi[k:].max(axis=0)
+        nodes[i]["offset"], nodes[i]["primitiveCount"], nodes[i]["axis"] = i + 2, 0, k % 3
+        nodes[i + 1]["boundsMin"], nodes[i + 1]["boundsMax"] = lo[k], hi[k]
+        nodes[i + 1]["offset"], nodes[i + 1]["primitiveCount"] = k, 1
+    nodes[-1]["boundsMin"], nodes[-1]["boundsMax"] = lo[n - 1], hi[n - 1]
+    nodes[-1]["offset"], nodes[-1]["primitiveCount"] = n - 1, 1
+    return sc.Scene(nodes=nodes.view(np.uint8).reshape(-1), prims=base.prims, materials=base.materials, lights=base.lights, camera=base.camera)
+
+
+def test_a_deep_callers_tree(monkeypatch):
+    """A chain of 40 leaves (height 39: the walks up the tree take that many steps) is prepared on the device like on the host; a
+    chain of 70 (deeper than the reference's 64-entry stack) is refused in the host's words."""
+    same(monkeypatch, chain_scene(40))
+    monkeypatch.setenv("LT_DEVICE_BUILD", "1")
+    r = RendererHIP(0)
+    with pytest.raises(C.LensTraceError, match="deeper than the reference's 64-entry traversal stack"):
+        r.set_scene(chain_scene(70))
+    r.set_scene(chain_scene(64))
+    assert r.scene_structure(3)[3] == 1 and r.stats is not None
+    r.close()
