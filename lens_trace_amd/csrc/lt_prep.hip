@@ -284,169 +284,203 @@ __device__ void emit_child(Range c, Range* __restrict__ nextBig, Range* __restri
 }
 
 // ------------------------------------------------------------------------------------------ at most 64 leaves: the whole subtree
-// Ranges of at most kSmall leaves -- seven in eight of a subtree's nodes -- do not fill bins: a plane that matters is the plane
-// behind some leaf's own bin (any other plane has the same two sides as the nearest such plane below it, hence the same cost,
-// and the host's sweep keeps the first of equals), so every leaf prices the three planes behind its own bins against the
-// range's leaves, read lane by lane.
-constexpr uint32_t kSmall = 8;
+// One wavefront, its leaves in registers, lane = position: a range of the subtree is a run of lanes [s, e), and what a lane keeps
+// beside its leaf is the run it stands in (s, e, the node the run will become, its depth).  A stable partition moves the leaves
+// between lanes (ds_permute); the runs stay where they are and are cut in two.  Two ways to split:
+//   * a run of more than kSmall leaves: one at a time, with wavefront-wide reductions and the 32 bins in LDS (sah_eval);
+//   * ALL runs of at most kSmall leaves at once -- seven in eight of a subtree's nodes --, every lane pricing the planes behind its
+//     own leaf's bins against the leaves of its own run, fetched lane by lane (ds_bpermute from s + j).  A plane that matters is
+//     the plane behind some leaf's bin: any other plane has the same two sides as the nearest such plane below it, hence the
+//     same cost, and the host's sweep keeps the first of equals.
+constexpr uint32_t kSmall = 16;
+
+__device__ __forceinline__ uint32_t from_lane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lane << 2), (int)v); }
+__device__ __forceinline__ uint32_t to_lane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_ds_permute((int)(lane << 2), (int)v); }
+__device__ __forceinline__ float to_lane_f(float v, uint32_t lane) { return __uint_as_float(to_lane(__float_as_uint(v), lane)); }
 
 __global__ __launch_bounds__(256) void k_tiny(const float4* __restrict__ nd, const uint32_t* __restrict__ order, const Range* __restrict__ list,
                                                const uint32_t* __restrict__ counts, float4* __restrict__ out, int heightLimit,
                                                uint32_t* __restrict__ ctl) {
   __shared__ uint32_t s_bins[4][kRangeBins];
-  __shared__ uint4 s_stack[4][66];
   const uint32_t wave = threadIdx.x >> 6, lane = lane_id(), w = blockIdx.x * 4 + wave;
   if (w >= counts[kCntTiny]) return;
   const Range rg = list[w];
   const uint32_t n = rg.end - rg.start;
-  const bool has = lane < n;
   Leaf l;
-  const uint32_t leaf = has ? order[rg.start + lane] : 0u;
+  uint32_t leaf = lane < n ? order[rg.start + lane] : 0u;
   load_leaf(nd, leaf, l);
   uint32_t olo[3], ohi[3], oc[3];
   for (int k = 0; k < 3; k++) { olo[k] = ordered(l.lo[k]); ohi[k] = ordered(l.hi[k]); oc[k] = ordered(l.c[k]); }
-  uint32_t pos = lane;   // relative position; lanes without a leaf keep their own (the positions stay a permutation of 0..63)
+  // the run this lane stands in; a lane beyond the range, or whose run is down to one leaf, stands in a run of its own
+  uint32_t rs = lane < n ? 0u : lane, re = lane < n ? n : lane + 1u, rnode = rg.node, rdepth = rg.depth;
   uint32_t* bins = s_bins[wave];
-  uint4* stack = s_stack[wave];
-  int sp = 0;
-  if (lane == 0) stack[0] = make_uint4(0u, n, rg.node, rg.depth);
-  sp = 1;
   uint32_t deepest = 0, bad = 0;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  while (sp > 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint4 top = stack[--sp];
-    const uint32_t s = top.x, e = top.y, node = top.z, depth = top.w, cnt = e - s;
-    const bool in = has && pos >= s && pos < e;
-    const uint64_t inMask = __ballot(in);
-    deepest = max(deepest, depth + 1);   // (two leaves at least: there is a level below)
+  const uint64_t laneBit = 1ull << lane, below = laneBit - 1ull;
+  for (int guard = 0; guard < 64; guard++) {
+    const uint32_t cnt = re - rs;
+    const uint64_t open = __ballot(cnt >= 2u), large = __ballot(cnt > kSmall);
+    if (open == 0ull) break;
     float lo[3], hi[3], cmin[3], cmax[3], d[3], scale[3];
-    if (cnt <= kSmall) {
-      uint32_t a[12];
-      for (int k = 0; k < 12; k++) a[k] = (k % 6) < 3 ? kMinIdentity : kMaxIdentity;
-      for (uint64_t m = inMask; m; m &= m - 1) {
-        const int src = __builtin_ctzll(m);
-        for (int k = 0; k < 3; k++) {
-          a[k] = min(a[k], read_lane(olo[k], src));
-          a[3 + k] = max(a[3 + k], read_lane(ohi[k], src));
-          const uint32_t c = read_lane(oc[k], src);
-          a[6 + k] = min(a[6 + k], c);
-          a[9 + k] = max(a[9 + k], c);
-        }
-      }
-      for (int k = 0; k < 3; k++) { lo[k] = unordered(a[k]); hi[k] = unordered(a[3 + k]); cmin[k] = unordered(a[6 + k]); cmax[k] = unordered(a[9 + k]); }
-    } else {
+    int myBin[3], dim = 0;
+    uint32_t left = cnt / 2u;
+    bool act, pred = false, split = false;
+    if (large != 0ull) {
+      // ---- one large run: the run of the first lane that stands in one
+      const int head = __builtin_ctzll(large);
+      const uint32_t s = read_lane(rs, head), e = read_lane(re, head), depth = read_lane(rdepth, head), c = e - s;
+      act = lane >= s && lane < e;
       for (int k = 0; k < 3; k++) {
-        lo[k] = unordered(wave_min_u(in ? olo[k] : kMinIdentity));
-        hi[k] = unordered(wave_max_u(in ? ohi[k] : kMaxIdentity));
-        cmin[k] = unordered(wave_min_u(in ? oc[k] : kMinIdentity));
-        cmax[k] = unordered(wave_max_u(in ? oc[k] : kMaxIdentity));
+        lo[k] = unordered(wave_min_u(act ? olo[k] : kMinIdentity));
+        hi[k] = unordered(wave_max_u(act ? ohi[k] : kMaxIdentity));
+        cmin[k] = unordered(wave_min_u(act ? oc[k] : kMinIdentity));
+        cmax[k] = unordered(wave_max_u(act ? oc[k] : kMaxIdentity));
+        d[k] = __fsub_rn(cmax[k], cmin[k]);
+        scale[k] = bin_scale(d[k]);
+        myBin[k] = bin_of(l.c[k], cmin[k], scale[k]);
       }
-    }
-    int myBin[3];
-    for (int k = 0; k < 3; k++) {
-      d[k] = __fsub_rn(cmax[k], cmin[k]);
-      scale[k] = bin_scale(d[k]);
-      myBin[k] = bin_of(l.c[k], cmin[k], scale[k]);
-    }
-    int dim = largest_extent(d);
-    uint32_t left = cnt / 2;
-    bool split = false, pred = false;
-    const uint32_t maxChild = max_child(cnt, heightLimit, depth);
-    if (cnt > 2 && maxChild >= (cnt + 1) / 2) {
-      int bestDim = -1, bestBin = -1;
-      if (cnt <= kSmall) {
-        float cost = __builtin_inff();
-        uint32_t idx = kNone;
-        for (int a = 0; a < 3; a++) {
-          if (!(d[a] > 0.0f)) continue;
-          uint32_t L[6] = {kMinIdentity, kMinIdentity, kMinIdentity, kMaxIdentity, kMaxIdentity, kMaxIdentity};
-          uint32_t R[6] = {kMinIdentity, kMinIdentity, kMinIdentity, kMaxIdentity, kMaxIdentity, kMaxIdentity};
-          uint32_t nL = 0;
-          for (uint64_t m = inMask; m; m &= m - 1) {
-            const int src = __builtin_ctzll(m);
-            const bool isL = (int)read_lane((uint32_t)myBin[a], src) <= myBin[a];
-            nL += isL ? 1u : 0u;
-            for (int k = 0; k < 3; k++) {
-              const uint32_t vl = read_lane(olo[k], src), vh = read_lane(ohi[k], src);
-              L[k] = isL ? min(L[k], vl) : L[k];
-              L[3 + k] = isL ? max(L[3 + k], vh) : L[3 + k];
-              R[k] = isL ? R[k] : min(R[k], vl);
-              R[3 + k] = isL ? R[3 + k] : max(R[3 + k], vh);
-            }
-          }
-          const uint32_t nR = cnt - nL;
-          if (in && myBin[a] < kBins - 1 && nR != 0 && nL <= maxChild && nR <= maxChild) {
-            float flo[3], fhi[3], glo[3], ghi[3];
-            for (int k = 0; k < 3; k++) { flo[k] = unordered(L[k]); fhi[k] = unordered(L[3 + k]); glo[k] = unordered(R[k]); ghi[k] = unordered(R[3 + k]); }
-            const float c = __fadd_rn(__fmul_rn(half_area(flo, fhi), (float)nL), __fmul_rn(half_area(glo, ghi), (float)nR));
-            const uint32_t i = (uint32_t)a * 32u + (uint32_t)myBin[a];
-            if (c < cost || (c == cost && i < idx)) { cost = c; idx = i; }
-          }
-        }
-        for (int m = 32; m; m >>= 1) {
-          const float oc2 = __shfl_xor(cost, m);
-          const uint32_t oi = (uint32_t)__shfl_xor((int)idx, m);
-          if (oc2 < cost || (oc2 == cost && oi < idx)) { cost = oc2; idx = oi; }
-        }
-        if (cost < 3.402823466e+38f && idx != kNone) { bestDim = (int)(idx >> 5); bestBin = (int)(idx & 31u); }
-      } else {
+      dim = largest_extent(d);
+      left = c / 2u;
+      const uint32_t maxChild = max_child(c, heightLimit, depth);
+      if (maxChild >= (c + 1u) / 2u) {
         clear_bins(bins);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (in) bin_leaf(bins, l, cmin, scale, d);
+        if (act) bin_leaf(bins, l, cmin, scale, d);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const Split sp2 = sah_eval(bins, d, maxChild);
-        bestDim = sp2.dim;
-        bestBin = sp2.bin;
+        const Split sp = sah_eval(bins, d, maxChild);
+        if (sp.dim >= 0) {
+          split = true;
+          dim = sp.dim;
+          pred = picki(myBin, dim) <= sp.bin;
+        }
       }
-      if (bestDim >= 0) {
-        split = true;
-        dim = bestDim;
-        pred = picki(myBin, dim) <= bestBin;
-        left = (uint32_t)__popcll(__ballot(in && pred));
+      if (!split) {
+        if (pick(d, dim) > 0.0f) {   // the c / 2 smallest (centroid, leaf index) go left
+          const uint32_t kh = dim == 0 ? oc[0] : (dim == 1 ? oc[1] : oc[2]);
+          uint32_t rank = 0;
+          for (uint64_t m = __ballot(act); m; m &= m - 1) {
+            const int src = __builtin_ctzll(m);
+            const uint32_t oh = read_lane(kh, src), ol = read_lane(leaf, src);
+            rank += (oh < kh || (oh == kh && ol < leaf)) ? 1u : 0u;
+          }
+          pred = rank < left;
+        } else {
+          pred = lane - s < left;
+        }
       }
-    }
-    if (!split) {
-      if (pick(d, dim) > 0.0f) {   // the cnt / 2 smallest (centroid, leaf index) go left
+    } else {
+      // ---- every run of 2 .. kSmall leaves at once
+      act = cnt >= 2u;
+      const uint32_t maxCnt = wave_max_u(act ? cnt : 0u);
+      uint32_t a[12];
+      for (int k = 0; k < 12; k++) a[k] = (k % 6) < 3 ? kMinIdentity : kMaxIdentity;
+      for (uint32_t j = 0; j < maxCnt; j++) {
+        const bool has = j < cnt;
+        const uint32_t src = has ? rs + j : lane;
+        for (int k = 0; k < 3; k++) {
+          const uint32_t vl = from_lane(olo[k], src), vh = from_lane(ohi[k], src), vc = from_lane(oc[k], src);
+          if (has) { a[k] = min(a[k], vl); a[3 + k] = max(a[3 + k], vh); a[6 + k] = min(a[6 + k], vc); a[9 + k] = max(a[9 + k], vc); }
+        }
+      }
+      for (int k = 0; k < 3; k++) {
+        lo[k] = unordered(a[k]); hi[k] = unordered(a[3 + k]); cmin[k] = unordered(a[6 + k]); cmax[k] = unordered(a[9 + k]);
+        d[k] = __fsub_rn(cmax[k], cmin[k]);
+        scale[k] = bin_scale(d[k]);
+        myBin[k] = bin_of(l.c[k], cmin[k], scale[k]);
+      }
+      dim = largest_extent(d);
+      const uint32_t maxChild = max_child(cnt, heightLimit, rdepth);
+      const bool wantsPlane = act && cnt > 2u && maxChild >= (cnt + 1u) / 2u;
+      float cost = __builtin_inff();
+      uint32_t idx = kNone;
+      if (__ballot(wantsPlane) != 0ull) {
+        for (int ax = 0; ax < 3; ax++) {
+          uint32_t L[6] = {kMinIdentity, kMinIdentity, kMinIdentity, kMaxIdentity, kMaxIdentity, kMaxIdentity};
+          uint32_t R[6] = {kMinIdentity, kMinIdentity, kMinIdentity, kMaxIdentity, kMaxIdentity, kMaxIdentity};
+          uint32_t nL = 0;
+          for (uint32_t j = 0; j < maxCnt; j++) {
+            const bool has = j < cnt;
+            const uint32_t src = has ? rs + j : lane;
+            const int ob = (int)from_lane((uint32_t)myBin[ax], src);
+            const bool isL = has && ob <= myBin[ax], isR = has && !(ob <= myBin[ax]);
+            nL += isL ? 1u : 0u;
+            for (int k = 0; k < 3; k++) {
+              const uint32_t vl = from_lane(olo[k], src), vh = from_lane(ohi[k], src);
+              L[k] = isL ? min(L[k], vl) : L[k];
+              L[3 + k] = isL ? max(L[3 + k], vh) : L[3 + k];
+              R[k] = isR ? min(R[k], vl) : R[k];
+              R[3 + k] = isR ? max(R[3 + k], vh) : R[3 + k];
+            }
+          }
+          const uint32_t nR = cnt - nL;
+          if (wantsPlane && d[ax] > 0.0f && myBin[ax] < kBins - 1 && nR != 0u && nL <= maxChild && nR <= maxChild) {
+            float flo[3], fhi[3], glo[3], ghi[3];
+            for (int k = 0; k < 3; k++) { flo[k] = unordered(L[k]); fhi[k] = unordered(L[3 + k]); glo[k] = unordered(R[k]); ghi[k] = unordered(R[3 + k]); }
+            const float c = __fadd_rn(__fmul_rn(half_area(flo, fhi), (float)nL), __fmul_rn(half_area(glo, ghi), (float)nR));
+            const uint32_t i = (uint32_t)ax * 32u + (uint32_t)myBin[ax];
+            if (c < cost || (c == cost && i < idx)) { cost = c; idx = i; }
+          }
+        }
+        // the run's best: the minimum over its lanes of (cost, plane)
+        float bc = cost;
+        uint32_t bi = idx;
+        for (uint32_t j = 0; j < maxCnt; j++) {
+          const bool has = j < cnt;
+          const uint32_t src = has ? rs + j : lane;
+          const float oc2 = __uint_as_float(from_lane(__float_as_uint(cost), src));
+          const uint32_t oi = from_lane(idx, src);
+          if (has && (oc2 < bc || (oc2 == bc && oi < bi))) { bc = oc2; bi = oi; }
+        }
+        if (wantsPlane && bc < 3.402823466e+38f && bi != kNone) {
+          split = true;
+          dim = (int)(bi >> 5);
+          pred = picki(myBin, dim) <= (int)(bi & 31u);
+        }
+      }
+      // the runs without a plane: the cnt / 2 smallest (centroid, leaf index) go left, or the first half as it stands
+      if (__ballot(act && !split) != 0ull) {
         const uint32_t kh = dim == 0 ? oc[0] : (dim == 1 ? oc[1] : oc[2]);
         uint32_t rank = 0;
-        for (uint64_t m = inMask; m; m &= m - 1) {
-          const int src = __builtin_ctzll(m);
-          const uint32_t oh = read_lane(kh, src), ol = read_lane(leaf, src);
-          rank += (oh < kh || (oh == kh && ol < leaf)) ? 1u : 0u;
+        for (uint32_t j = 0; j < maxCnt; j++) {
+          const bool has = j < cnt;
+          const uint32_t src = has ? rs + j : lane;
+          const uint32_t oh = from_lane(kh, src), ol = from_lane(leaf, src);
+          rank += (has && (oh < kh || (oh == kh && ol < leaf))) ? 1u : 0u;
         }
-        pred = rank < left;
-      } else {
-        pred = pos - s < left;
+        if (!split) pred = pick(d, dim) > 0.0f ? rank < left : lane - rs < left;
       }
     }
-    // stable partition in position space: lane p learns whether the leaf AT position p goes left
-    const int flagAt = __builtin_amdgcn_ds_permute((int)(pos << 2), (in && pred) ? 1 : 0);
-    const uint64_t posMask = __ballot(flagAt != 0);
-    const uint64_t rangeMask = (e >= 64 ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << s) - 1ull);
-    const uint64_t L = posMask & rangeMask, Rm = ~posMask & rangeMask, below = (1ull << pos) - 1ull;
-    if ((uint32_t)__popcll(L) != left || left == 0 || left >= cnt) bad = 1;
-    if (bad) break;
-    if (in) pos = pred ? s + (uint32_t)__popcll(L & below) : s + left + (uint32_t)__popcll(Rm & below);
-    const uint32_t rightNode = node + 2u * left, right = cnt - left;
-    // a child of one leaf is written by the lane that holds it; larger children wait on the stack
-    if (in && ((left == 1 && pos == s) || (right == 1 && pos == s + left))) {
-      const uint32_t at = pos == s ? node + 1 : rightNode;
-      out[2 * (size_t)at] = l.a;
-      out[2 * (size_t)at + 1] = l.b;
+    // ---- the stable partition of the runs that took part: a leaf's new lane from the lanes of its run below it, the runs cut in two
+    const uint64_t mL = __ballot(act && pred), mR = __ballot(act && !pred);
+    const uint64_t runMask = (re >= 64u ? ~0ull : ((1ull << re) - 1ull)) & ~((1ull << rs) - 1ull);
+    if (act) left = (uint32_t)__popcll(mL & runMask);
+    if (act && (left == 0u || left >= re - rs)) bad = 1;
+    if (__ballot(bad != 0u) != 0ull) { bad = 1; break; }
+    const uint32_t dest = !act ? lane : (pred ? rs + (uint32_t)__popcll(mL & runMask & below) : rs + left + (uint32_t)__popcll(mR & runMask & below));
+    if (act && lane == rs) store_interior(out, rnode, lo, hi, rnode + 2u * left, dim);
+    leaf = to_lane(leaf, dest);
+    l.a = make_float4(to_lane_f(l.a.x, dest), to_lane_f(l.a.y, dest), to_lane_f(l.a.z, dest), to_lane_f(l.a.w, dest));
+    l.b = make_float4(to_lane_f(l.b.x, dest), to_lane_f(l.b.y, dest), to_lane_f(l.b.z, dest), to_lane_f(l.b.w, dest));
+    l.lo[0] = l.a.x; l.lo[1] = l.a.y; l.lo[2] = l.a.z;
+    l.hi[0] = l.a.w; l.hi[1] = l.b.x; l.hi[2] = l.b.y;
+    for (int k = 0; k < 3; k++) {
+      l.c[k] = __fadd_rn(__fmul_rn(0.5f, l.lo[k]), __fmul_rn(0.5f, l.hi[k]));
+      olo[k] = ordered(l.lo[k]); ohi[k] = ordered(l.hi[k]); oc[k] = ordered(l.c[k]);
     }
-    if (lane == 0) {
-      store_interior(out, node, lo, hi, rightNode, dim);
-      uint32_t q = sp;
-      if (right > 1) stack[q++] = make_uint4(s + left, e, rightNode, depth + 1);
-      if (left > 1) stack[q] = make_uint4(s, s + left, node + 1, depth + 1);
+    if (act) {
+      deepest = max(deepest, rdepth + 1u);
+      if (lane < rs + left) { re = rs + left; rnode = rnode + 1u; }
+      else { rnode = rnode + 2u * left; rs = rs + left; }
+      rdepth++;
+      if (re - rs == 1u) {   // a run of one: the leaf's node
+        out[2 * (size_t)rnode] = l.a;
+        out[2 * (size_t)rnode + 1] = l.b;
+      }
     }
-    sp += (right > 1 ? 1 : 0) + (left > 1 ? 1 : 0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (sp > 64) { bad = 1; break; }
   }
+  deepest = wave_max_u(deepest);
+  bad |= __ballot(re - rs >= 2u) != 0ull ? 1u : 0u;   // (64 rounds cut any 64 leaves into single ones)
   if (lane == 0) {
     raise_max(&ctl[kCtlOwnHeight], deepest);
     if (bad) atomicOr(&ctl[kCtlFlags], (uint32_t)kFlagInternal);
