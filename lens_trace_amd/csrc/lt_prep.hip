@@ -796,14 +796,47 @@ __global__ __launch_bounds__(256) void k_big_bins(const float4* __restrict__ nd,
   read_bounds(acc, c.r, b);
   __syncthreads();
   {
+    // a thread takes eight CONSECUTIVE leaves of the chunk: neighbours in the order are neighbours in space (the caller's
+    // pre-order, kept by the stable partitions), so they mostly fall into one bin -- the thread unites them in registers and
+    // sends a bin's seven atomics when the bin changes (a wavefront's 64 leaves one by one would queue up on one LDS word each)
     ChunkLeaves cl;
-    load_chunk(nd, order, c.s, c.e, cl);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      if (cl.leaf[j] == kNone) continue;
-      Leaf l;
-      leaf_of(cl, j, l);
-      bin_leaf(s_bins, l, b.cmin, b.scale, b.d);
+      const uint32_t i = c.s + threadIdx.x * 8u + (uint32_t)j;
+      cl.leaf[j] = i < c.e ? order[i] : kNone;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t at = cl.leaf[j] != kNone ? cl.leaf[j] : 0u;
+      cl.a[j] = nd[2 * (size_t)at];
+      cl.b[j] = nd[2 * (size_t)at + 1];
+    }
+    for (int a = 0; a < 3; a++) {
+      if (!(b.d[a] > 0.0f)) continue;
+      int cur = -1;
+      uint32_t acc[6] = {kMinIdentity, kMinIdentity, kMinIdentity, kMaxIdentity, kMaxIdentity, kMaxIdentity}, count = 0;
+      auto flush = [&]() {
+        if (cur < 0) return;
+        uint32_t* w = s_bins + (a * 32 + cur) * kBinWords;
+        for (int k = 0; k < 3; k++) { atomicMin(&w[k], acc[k]); atomicMax(&w[3 + k], acc[3 + k]); }
+        atomicAdd(&w[6], count);
+      };
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (cl.leaf[j] == kNone) continue;
+        Leaf l;
+        leaf_of(cl, j, l);
+        const int bin = bin_of(l.c[a], b.cmin[a], b.scale[a]);
+        if (bin != cur) {
+          flush();
+          cur = bin;
+          for (int k = 0; k < 3; k++) { acc[k] = kMinIdentity; acc[3 + k] = kMaxIdentity; }
+          count = 0;
+        }
+        for (int k = 0; k < 3; k++) { acc[k] = min(acc[k], ordered(l.lo[k])); acc[3 + k] = max(acc[3 + k], ordered(l.hi[k])); }
+        count++;
+      }
+      flush();
     }
   }
   __syncthreads();
