@@ -590,14 +590,45 @@ __device__ void k_mid_range(const float4* __restrict__ nd, const uint32_t* __res
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (uint32_t base = rg.start; base < rg.end; base += 256) {
+      // (four CONSECUTIVE leaves per lane, united in registers while the bin stays: see k_big_bins)
       WaveLeaves wl;
-      load_wave(nd, orderIn, base, rg.end, wl);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        if (wl.leaf[j] == kNone) continue;
-        Leaf l;
-        leaf_of(wl, j, l);
-        bin_leaf(bins, l, cmin, scale, d);
+        const uint32_t i = base + lane * 4u + (uint32_t)j;
+        wl.leaf[j] = i < rg.end ? orderIn[i] : kNone;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t at = wl.leaf[j] != kNone ? wl.leaf[j] : 0u;
+        wl.a[j] = nd[2 * (size_t)at];
+        wl.b[j] = nd[2 * (size_t)at + 1];
+      }
+      for (int a = 0; a < 3; a++) {
+        if (!(d[a] > 0.0f)) continue;
+        int cur = -1;
+        uint32_t acc[6] = {kMinIdentity, kMinIdentity, kMinIdentity, kMaxIdentity, kMaxIdentity, kMaxIdentity}, count = 0;
+        auto flush = [&]() {
+          if (cur < 0) return;
+          uint32_t* w = bins + (a * 32 + cur) * kBinWords;
+          for (int k = 0; k < 3; k++) { atomicMin(&w[k], acc[k]); atomicMax(&w[3 + k], acc[3 + k]); }
+          atomicAdd(&w[6], count);
+        };
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (wl.leaf[j] == kNone) continue;
+          Leaf l;
+          leaf_of(wl, j, l);
+          const int bin = bin_of(l.c[a], cmin[a], scale[a]);
+          if (bin != cur) {
+            flush();
+            cur = bin;
+            for (int k = 0; k < 3; k++) { acc[k] = kMinIdentity; acc[3 + k] = kMaxIdentity; }
+            count = 0;
+          }
+          for (int k = 0; k < 3; k++) { acc[k] = min(acc[k], ordered(l.lo[k])); acc[3 + k] = max(acc[3 + k], ordered(l.hi[k])); }
+          count++;
+        }
+        flush();
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
