@@ -189,7 +189,7 @@ int lt_hip_resolve_program(lt_hip_context* ctx, const char* kernel_file_path, in
  * (renderer_opencl.cpp:107-120), and in-place edits are honoured.
  * Derived at upload: the traversal-side triangle array (48-byte stride: A, B-A, C-A) and -- when every node's box encloses
  * its children's, which the reference's own builder guarantees -- the backend's OWN hierarchy over the caller's leaves
- * (binned surface-area heuristic, built by kernels -- lens_trace_amd/csrc/lt_prep.hip: ~8 ms for the whole call on a million
+ * (binned surface-area heuristic, built by kernels -- lens_trace_amd/csrc/lt_prep.hip: ~6.5 ms for the whole call on a million
  * triangles -- or, for small or unusual buffers, by host threads: lt_retree.hpp), the 64-byte records of its packet
  * walks, the 4-wide groups of quantised boxes and the leaf records of its per-lane walks and the reference's leaf order per
  * direction-sign octant.  The caller's LinearBVHNode array stays resident and is
