@@ -548,13 +548,15 @@ static int validate_scene(const uint8_t* nodes, uint32_t n_nodes, const uint8_t*
 }
 
 // Host threads for the memory-bound host passes of lt_hip_set_scene (content hash): what the process may run on
-// (sched_getaffinity: a container's CPU share, not the machine's core count), at most 32.
+// (sched_getaffinity: a container's CPU share, not the machine's core count), at most 16 unless LT_HOST_THREADS says otherwise
+// (140 MB on the GPU box's host: 2.5 ms on 2 threads, 0.85 on 8, 0.70 on 12-16, 1.1 on 32 -- starting a thread costs what it
+// hashes in 30 microseconds; tests/tools/hash_threads.py).
 static int host_threads() {
   cpu_set_t set;
   int n = 1;
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(16, CPU_COUNT(&set));
   if (const char* e = getenv("LT_HOST_THREADS")) n = atoi(e);
-  return std::max(1, std::min(32, n));
+  return std::max(1, std::min(64, n));
 }
 
 // 64-bit content hash of a host buffer: four independent multiply-rotate lanes over 32-byte blocks, per 4 MiB piece; the pieces'
