@@ -361,3 +361,37 @@ def test_quantised_test_accepts_whenever_the_reference_accepts_the_true_box(scal
     # (a scene far from the origin relative to its size pays for it: the boxes' outward push and the test's margin are relative
     # to the coordinates' magnitude, 2^-21 of 3000 against boxes of 0.02 -- looser tests, never wrong ones)
     assert (ok & con & ~ref).sum() <= (1.0 if centre > 100.0 else 0.02) * max(1, (ok & ref).sum()) + 5
+
+
+def test_box_unions_take_one_order_of_the_floats_and_the_median_rule_is_a_function_of_the_set():
+    """What makes the device-side build (lt_prep.hip, held against this one byte for byte on the GPU) possible: (1) unions are taken
+    in ONE total order of the floats, -0 below +0 (the integers the kernels' atomic min / max work on), so an interior bound's zero
+    has the sign that order gives it whatever the order of the leaves; (2) where no plane separates the centroids (coincident
+    ones; two leaves) the count / 2 smallest (centroid, leaf index) go left and both halves keep the order they stood in -- the
+    same tree for any permutation of equal-centroid leaves' boxes that keeps their indices."""
+    # (1) signed zeros: leaves whose bounds are +0.0 and -0.0 on one axis, in both orders
+    lo = np.array([[-0.0, 1.0, 1.0], [0.0, 2.0, 2.0], [0.5, 3.0, 3.0], [-0.0, 4.0, 4.0]], dtype=f32)
+    hi = np.array([[0.0, 1.5, 1.5], [-0.0, 2.5, 2.5], [0.75, 3.5, 3.5], [0.0, 4.5, 4.5]], dtype=f32)
+    roots = []
+    for perm in ([0, 1, 2, 3], [1, 0, 3, 2], [3, 2, 1, 0]):
+        h, own, _ = C.own_hierarchy(chain_tree(lo[perm], hi[perm]), 4, 2)
+        assert h >= 1
+        roots.append((own["boundsMin"][0].view(np.uint32).tolist(), own["boundsMax"][0].view(np.uint32).tolist()))
+    assert roots[0] == roots[1] == roots[2]
+    assert roots[0][0][0] == 0x80000000 and roots[0][1][0] == 0x3f400000      # min = -0.0 (below +0.0), max = 0.75
+    # (2) coincident centroids: 64 boxes around one point (different extents), then around two points
+    rng = np.random.default_rng(4)
+    for centres in (np.zeros((64, 3)), np.repeat(np.array([[0.0, 0, 0], [3.0, 1, 2]]), 32, axis=0)):
+        half = rng.uniform(0.1, 1.0, (64, 3))
+        blo, bhi = (centres - half).astype(f32), (centres + half).astype(f32)
+        assert np.array_equal((0.5 * blo + 0.5 * bhi).astype(f32), centres.astype(f32))     # exactly coincident centroids
+        h, own, _ = C.own_hierarchy(chain_tree(blo, bhi), 64, 2)
+        assert 6 <= h <= 8
+        check_tree(own, h)
+        # leaves under the root's left child: the first half of the caller's order (coincident: "the first half as it stands")
+        leaf = own["primitiveCount"] != 0
+        if np.all(centres == 0):
+            left = np.arange(1, int(own["offset"][0]))
+            assert sorted(own["offset"][left][leaf[left]].tolist()) == list(range(32))
+        h2, own2, _ = C.own_hierarchy(chain_tree(blo, bhi), 64, 2)
+        assert np.array_equal(own.view(np.uint8), own2.view(np.uint8))
