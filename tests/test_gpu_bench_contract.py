@@ -59,6 +59,9 @@ def test_two_ranks_on_one_gpu_through_gloo_count_the_same_rays():
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
     # two steps in flight: the period of finished frames and one frame's own latency are two numbers
     assert two["config"]["steps_in_flight"] == 2 and two["config"]["frame_latency_ms"] > 0 and two["config"]["kernel_only_mrays_per_s"] is None
+    # ... and the shadow-ray walk was chosen the way the steps run (two in flight), not from one launch alone
+    pc = two["config"]["shadow_ray_walk_pipelined"]
+    assert pc["pinned"] in ("library verdict", "1", "0") and min(pc["ms_per_step_packets"], pc["ms_per_step_per_lane"], pc["ms_per_step_library_verdict"]) > 0
     assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
     assert "tiles interleaved over 2 GPUs" in two["config"]["workload"]
     assert "cpu_baseline" not in two
