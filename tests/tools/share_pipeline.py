@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 for world in (8, 4):
     plan = TilePlan.balanced(W, H, D, world, 64)
     d = make_desc(prog, W, H, D, scene.camera, frame_first=1, frame_count=SPP, accumulate=True, accumulate_base=0, tile=plan.desc_tile(0))
-    for depth in (1, 2):
+    for depth in [int(x) for x in os.environ.get("LT_DEPTHS", "1,2").split(",")]:
         rs = [RendererHIP(0) for _ in range(depth)]
         streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
         bufs = [torch.zeros(plan.floats_per_rank, dtype=torch.float32, device=dev) for _ in range(depth)]
