@@ -135,8 +135,8 @@ __global__ void lt_untile_kernel(const float* __restrict__ gathered, uint64_t fl
 // read-modify-write of render_square, so the result is bit for bit what n single-sample launches leave behind.  Pixels of
 // edge tiles that lie outside the image are not touched (render_square never writes them).
 __global__ void lt_running_mean_kernel(const float* __restrict__ samples, uint32_t n, uint64_t stride, float* __restrict__ out,
-                                       uint64_t floats, int32_t base, FrameParams fp, int checkPadding) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                       uint64_t first, uint64_t floats, int32_t base, FrameParams fp, int checkPadding) {
+  const uint64_t i = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (this launch folds the floats [first, floats))
   if (i >= floats) return;
   if (i % fp.depth >= 3u) return;   // render_square / the GI resolve stage write channels 0..2 only; the others are the caller's
   if (checkPadding) {
@@ -250,6 +250,10 @@ struct lt_hip_context {
   void* h_out = nullptr;             // ... and its pinned host twin: the read-back lands here at the link's rate, piece by piece
   uint64_t h_out_bytes = 0;          //     (a caller's pageable buffer would be read back through the runtime's small bounce buffers)
   hipEvent_t out_ev[8] = {};         // one event per piece
+  hipEvent_t fold_ev[8] = {};        // ... and one behind the fold of each piece (launch_running_mean), when the call's last fold is cut into them
+  uint64_t fold_piece_bytes = 0;     //     (set by lt_hip_render around its render: bytes per piece, 0 = one fold launch)
+  bool fold_pieced = false;
+  hipStream_t copy_stream = nullptr; //     the pieces travel on a stream of their own, each behind its fold
   unsigned long long* d_stats = nullptr;
   uint32_t* d_queues = nullptr;      // persistent mode: 8 per-XCD work counters per launch of a call
   uint32_t queue_frames = 0;
@@ -368,6 +372,8 @@ extern "C" int lt_hip_destroy(lt_hip_context* ctx) {
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);
   for (hipEvent_t e : ctx->out_ev) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->fold_ev) if (e) (void)hipEventDestroy(e);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
   if (ctx->d_queues) (void)hipFree(ctx->d_queues);
   if (ctx->d_samples) (void)hipFree(ctx->d_samples);
@@ -1340,7 +1346,7 @@ static int launch_gi_sets(lt_hip_context* ctx, hipStream_t s, const SceneDev& sc
 // Folds the nf sample images a fused launch left in ctx->d_samples into `out` (timed by its own event pair, so that
 // lt_hip_stats::render_ms can leave it out).
 static int launch_running_mean(lt_hip_context* ctx, hipStream_t s, const FrameParams& fp, uint64_t floats, uint32_t nf, int32_t base,
-                               bool paddedTiles, float* out) {
+                               bool paddedTiles, float* out, bool lastOfCall) {
   const uint32_t threads = 256;
   while (ctx->mean_events.size() < 2 * (size_t)(ctx->mean_pairs + 1)) {
     hipEvent_t e;
@@ -1348,8 +1354,24 @@ static int launch_running_mean(lt_hip_context* ctx, hipStream_t s, const FramePa
     ctx->mean_events.push_back(e);
   }
   LT_HIP_CHECK(ctx, hipEventRecord(ctx->mean_events[2 * ctx->mean_pairs], s));
-  lt_running_mean_kernel<<<dim3((uint32_t)((floats + threads - 1) / threads)), dim3(threads), 0, s>>>(ctx->d_samples, nf, floats, out, floats,
-                                                                                                  base, fp, paddedTiles ? 1 : 0);
+  ctx->fold_pieced = false;
+  if (lastOfCall && ctx->fold_piece_bytes != 0 && out == ctx->d_out && s == ctx->stream) {
+    // lt_hip_render: the call's last fold in the eight pieces of the read-back, an event behind each, so that piece k travels
+    // (enqueue_readback, on the copy stream) while piece k + 1 is folded
+    for (hipEvent_t& e : ctx->fold_ev) if (!e) LT_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const uint64_t per = ctx->fold_piece_bytes / sizeof(float);
+    for (int k = 0; k < 8; k++) {
+      const uint64_t lo = std::min(floats, (uint64_t)k * per), hi = std::min(floats, lo + per);
+      if (hi > lo)
+        lt_running_mean_kernel<<<dim3((uint32_t)((hi - lo + threads - 1) / threads)), dim3(threads), 0, s>>>(ctx->d_samples, nf, floats, out, lo, hi, base, fp,
+                                                                                                         paddedTiles ? 1 : 0);
+      LT_HIP_CHECK(ctx, hipEventRecord(ctx->fold_ev[k], s));
+    }
+    ctx->fold_pieced = true;
+  } else {
+    lt_running_mean_kernel<<<dim3((uint32_t)((floats + threads - 1) / threads)), dim3(threads), 0, s>>>(ctx->d_samples, nf, floats, out, 0ull, floats,
+                                                                                                    base, fp, paddedTiles ? 1 : 0);
+  }
   LT_HIP_CHECK(ctx, hipGetLastError());
   LT_HIP_CHECK(ctx, hipEventRecord(ctx->mean_events[2 * ctx->mean_pairs + 1], s));
   ctx->mean_pairs++;
@@ -1708,7 +1730,7 @@ static int render_on_stream(lt_hip_context* ctx, const lt_hip_render_desc* d, fl
       LT_HIP_CHECK(ctx, hipGetLastError());
       launches++;
       if (fused) {
-        const int mrc = launch_running_mean(ctx, s, fp, p.floats, nf, (int32_t)(d->accumulate_base + firstFrame), paddedTiles, out_device);
+        const int mrc = launch_running_mean(ctx, s, fp, p.floats, nf, (int32_t)(d->accumulate_base + firstFrame), paddedTiles, out_device, f >= frames);
         if (mrc) return mrc;
       }
     }
@@ -1788,10 +1810,16 @@ static int enqueue_readback(lt_hip_context* ctx, uint64_t need, float* out_host,
   }
   for (hipEvent_t& e : ctx->out_ev) if (!e) LT_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const uint64_t piece = ((need + 7) / 8 + 4095) / 4096 * 4096;
+  hipStream_t cs = ctx->stream;
+  if (ctx->fold_pieced && ctx->fold_piece_bytes == piece) {   // (the frame's last fold came in these pieces: each travels behind its own)
+    if (!ctx->copy_stream) LT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    cs = ctx->copy_stream;
+  }
   for (int k = 0; k < 8; k++) {
     const uint64_t off = std::min(need, (uint64_t)k * piece), n = std::min(piece, need - off);
-    if (n) LT_HIP_CHECK(ctx, hipMemcpyAsync((char*)ctx->h_out + off, (const char*)ctx->d_out + off, n, hipMemcpyDeviceToHost, ctx->stream));
-    LT_HIP_CHECK(ctx, hipEventRecord(ctx->out_ev[k], ctx->stream));
+    if (cs != ctx->stream) LT_HIP_CHECK(ctx, hipStreamWaitEvent(cs, ctx->fold_ev[k], 0));
+    if (n) LT_HIP_CHECK(ctx, hipMemcpyAsync((char*)ctx->h_out + off, (const char*)ctx->d_out + off, n, hipMemcpyDeviceToHost, cs));
+    LT_HIP_CHECK(ctx, hipEventRecord(ctx->out_ev[k], cs));
   }
   return LT_OK;
 }
@@ -1822,6 +1850,7 @@ static int finish_readback(lt_hip_context* ctx, uint64_t need, float* out_host, 
   for (std::thread& th : pool) th.join();
   for (int t = started; t < threads; t++) work(t, threads);   // (the slices of the threads that could not be had)
   LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->copy_stream) LT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));
   if (failed) return fail(ctx, LT_ERR_HIP, "read-back failed");
   return LT_OK;
 }
@@ -1847,9 +1876,15 @@ static int render_to_host(lt_hip_context* ctx, const lt_hip_render_desc* desc, f
     LT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_out, out_host, need, hipMemcpyHostToDevice, ctx->stream));
   else
     LT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_out, 0, need, ctx->stream));
+  {   // (the pieces of the read-back, for the call's last fold: enqueue_readback's arithmetic; LT_PINNED_READBACK=0: one piece, one fold)
+    const char* pe = getenv("LT_PINNED_READBACK");
+    ctx->fold_piece_bytes = (!(pe && atoi(pe) == 0) && need >= (1u << 20)) ? ((need + 7) / 8 + 4095) / 4096 * 4096 : 0;
+  }
+  ctx->fold_pieced = false;
   rc = render_on_stream(ctx, desc, ctx->d_out, need, ctx->stream);
-  if (rc) return rc;
-  return enqueue_readback(ctx, need, out_host, staged);
+  if (rc == LT_OK) rc = enqueue_readback(ctx, need, out_host, staged);
+  ctx->fold_piece_bytes = 0;
+  return rc;
 }
 
 extern "C" int lt_hip_render(lt_hip_context* ctx, const lt_hip_render_desc* desc, float* out_host, uint64_t out_bytes) {
